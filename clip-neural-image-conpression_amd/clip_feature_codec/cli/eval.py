@@ -1,0 +1,155 @@
+"""``python -m clip_feature_codec.cli.eval`` -- store evaluation, batched and sharded over the GPUs of a node.
+
+Reference surface kept (cli/eval.py:33-86): flags ``--store_dir --weights --size --steps --eta --device
+--out_json``; the four ``Average ...`` lines; the JSON list of ``{image, psnr, ssim, lpips, clip_sim}``
+in manifest order; NaN-filtered means.  What differs, because the reference reconstructs one image
+at a time on one device:
+
+* records are processed ``--batch`` (8) at a time through the fused DDIM graph;
+* under ``torchrun`` (one process per GPU) rank r takes manifest records ``r::world``; there is no
+  communication inside the loop, and ONE all-gather (RCCL over xGMI, ``backend='nccl'``) of the
+  per-record metric rows at the end; rank 0 prints / writes;
+* ``--seed`` makes start noise reproducible and independent of the sharding (record i always gets
+  the CPU-generator stream ``seed+i``); without it noise is unseeded like the reference;
+* originals are decoded / resized on host threads while the GPU samples.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..eval.metrics import psnr, ssim, lpips_distance, clip_similarity
+
+METRIC_KEYS = ("psnr", "ssim", "lpips", "clip_sim")
+
+
+def shard_indices(n: int, rank: int, world: int) -> List[int]:
+    """Records of rank ``rank``: the strided slice rank::world (independent units, no exchange)."""
+    return list(range(rank, n, world))
+
+
+def load_original(path: str, size: int) -> np.ndarray:
+    img = Image.open(path).convert("RGB").resize((size, size), Image.BICUBIC)
+    return (np.array(img).astype(np.float32) / 127.5 - 1.0).transpose(2, 0, 1)
+
+
+def metric_row(orig: np.ndarray, recon: np.ndarray, device: str) -> List[float]:
+    return [psnr(orig, recon), ssim(orig, recon), lpips_distance(orig, recon, device=device),
+            clip_similarity(orig, recon, device=device)]
+
+
+def gather_metric_rows(local_idx: Sequence[int], local_rows: np.ndarray, n_total: int, device: str) -> np.ndarray:
+    """One all-gather of [n_pad, 1+4] fp32 blocks (index, 4 metrics); returns (n_total, 4) in manifest order."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    out = np.full((n_total, len(METRIC_KEYS)), np.nan, dtype=np.float64)
+    if world == 1:
+        for i, row in zip(local_idx, local_rows):
+            out[i] = row
+        return out
+    n_pad = (n_total + world - 1) // world
+    block = torch.full((n_pad, 1 + len(METRIC_KEYS)), float("nan"), dtype=torch.float64)
+    block[:, 0] = -1
+    for k, (i, row) in enumerate(zip(local_idx, local_rows)):
+        block[k, 0] = i
+        block[k, 1:] = torch.as_tensor(row, dtype=torch.float64)
+    block = block.to(device)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    for blk in blocks:
+        for row in blk.cpu().numpy():
+            if row[0] >= 0:
+                out[int(row[0])] = row[1:]
+    return out
+
+
+def aggregate(rows: np.ndarray) -> dict:
+    """NaN-filtered mean per metric (cli/eval.py:77-79)."""
+    res = {}
+    for k, key in enumerate(METRIC_KEYS):
+        vals = rows[:, k][~np.isnan(rows[:, k])]
+        res[key] = float(np.mean(vals)) if vals.size else float("nan")
+    return res
+
+
+def evaluate(manifest: List[dict], z_of: Callable[[dict], np.ndarray], reconstruct: Callable, size: int, batch: int,
+             seed: Optional[int], rank: int, world: int, device: str, start_noise_fn: Callable) -> np.ndarray:
+    """Shard, reconstruct in batches, score on the host, gather.  ``reconstruct(z, x_T) -> (b,3,S,S)`` numpy in [-1,1]."""
+    mine = shard_indices(len(manifest), rank, world)
+    rows: List[List[float]] = []
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        for lo in range(0, len(mine), batch):
+            idx = mine[lo:lo + batch]
+            originals = [pool.submit(load_original, manifest[i]["image"], size) for i in idx]
+            z = np.concatenate([z_of(manifest[i]) for i in idx], 0)
+            recon = reconstruct(z, start_noise_fn(idx, size, seed))
+            futs = [pool.submit(metric_row, o.result(), recon[k], device) for k, o in enumerate(originals)]
+            rows += [f.result() for f in futs]
+    local = np.asarray(rows, dtype=np.float64).reshape(len(mine), len(METRIC_KEYS))
+    return gather_metric_rows(mine, local, len(manifest), device)
+
+
+def main(argv=None) -> None:
+    ap = argparse.ArgumentParser(description="Evaluate reconstruction quality on a store of images (MI355X build).")
+    ap.add_argument("--store_dir", type=str, required=True)
+    ap.add_argument("--weights", type=str, required=True)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--eta", type=float, default=0.0)
+    ap.add_argument("--device", type=str, default=None)
+    ap.add_argument("--out_json", type=str, default=None)
+    ap.add_argument("--batch", type=int, default=8, help="records per fused DDIM launch per GPU")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    args = ap.parse_args(argv)
+
+    from ._common import pick_device, load_codec_meta, load_embedding, build_model, build_sampler, start_noise
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = pick_device(args.device)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+
+    store_dir = Path(args.store_dir)
+    manifest = json.loads((store_dir / "manifest.json").read_text(encoding="utf-8"))
+    scale, zero = load_codec_meta(store_dir)
+    net = build_model(args.weights, device, scale.shape[0], args.dtype)
+    sampler = build_sampler(args.eta, device)
+
+    def reconstruct(z: np.ndarray, x_T: Optional[torch.Tensor]) -> np.ndarray:
+        zt = torch.from_numpy(z).to(device)
+        with torch.no_grad():
+            x = sampler.sample(net, zt, shape=(zt.shape[0], 3, args.size, args.size), steps=args.steps,
+                               x_T=None if x_T is None else x_T.to(device))
+        return x.clamp(-1, 1).cpu().numpy()
+
+    rows = evaluate(manifest, lambda rec: load_embedding(Path(rec["bitstream"]), scale, zero), reconstruct,
+                    args.size, args.batch, args.seed, rank, world, device, start_noise)
+    if rank == 0:
+        agg = aggregate(rows)
+        print(f"Average PSNR: {agg['psnr']:.2f} dB")
+        print(f"Average SSIM: {agg['ssim']:.4f}")
+        print(f"Average LPIPS: {agg['lpips']:.4f}")
+        print(f"Average CLIP similarity: {agg['clip_sim']:.4f}")
+        if args.out_json:
+            recs = [dict(image=manifest[i]["image"], **{k: float(rows[i, j]) for j, k in enumerate(METRIC_KEYS)})
+                    for i in range(len(manifest))]
+            with open(args.out_json, "w", encoding="utf-8") as f:
+                json.dump(recs, f, ensure_ascii=False, indent=2)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""DDIMSampler: the reference's ``DDIMSampler(scheduler, eta).sample(...)`` on the MI355X path.
+
+Interface of ``diffusion/ddim.py:14-45`` of the reference.  Two execution routes, same numbers:
+
+* fused  -- ``model`` is this package's ``CLIPCondUNet`` and ``eta == 0``: the timestep table and the
+  per-step coefficients are computed on the host (no ``.item()`` syncs inside the loop), conditioning
+  for all steps is hoisted in front of the loop, and the ``steps`` UNet evaluations + DDIM updates
+  replay as ONE captured hipGraph (``ccn_sample``).
+* stepwise -- any other callable ``model(x, z, t)`` or ``eta > 0``: one ``model`` call and one
+  ``ccn_ddim_step`` kernel per step; the ``eta > 0`` noise comes from ``torch.randn_like`` on the device.
+
+Reference behaviours kept on purpose: ``ts = linspace(T-1, 0, steps).long()``; ``alpha_bar_prev`` is
+``alphas_cumprod_prev[t]`` (not the next sampled step) and 1.0 on the last step; the direction term is
+``sqrt(alpha_bar_s - sigma^2) * eps``; ``x0`` is clamped to [-1, 1]; ``cfg_scale`` is accepted and unused;
+the result is NOT clamped; the output lives on ``z_clip.device``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _native
+
+
+class DDIMSampler:
+    """Deterministic (eta = 0) / stochastic DDIM sampler."""
+
+    def __init__(self, scheduler, eta: float = 0.0) -> None:
+        self.sch = scheduler
+        self.eta = eta
+        self.use_graph = True
+
+    @torch.no_grad()
+    def sample(self, model, z_clip: torch.Tensor, shape: tuple, steps: int = 50, cfg_scale: float = 1.0,
+               x_T: Optional[torch.Tensor] = None) -> torch.Tensor:
+        device = z_clip.device
+        if device.type != "cuda":
+            raise RuntimeError(f"z_clip is on {device}: DDIMSampler (MI355X build) needs a HIP device; no CPU fallback")
+        ts = self.sch.ddim_timesteps(steps)
+        coef = self.sch.ddim_coefficients(steps, self.eta)
+        x = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
+        if self.eta == 0 and hasattr(model, "sample_ddim"):
+            return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph)
+        x = _native.require_dev(x, "x_T").clone()
+        for i in range(steps):
+            t_b = torch.full((shape[0],), int(ts[i]), device=device, dtype=torch.long)
+            eps = model(x, z_clip, t_b)
+            sigma = float(coef[i, 4])
+            noise = torch.randn_like(x) if (self.eta > 0 and sigma > 0) else None
+            _native.ddim_step(x, eps, coef[i, :4], sigma, noise)
+        return x

@@ -1,0 +1,945 @@
+// Host side of libccn_hip.so: the C ABI of include/ccn_hip.h.
+//
+// A handle owns the repacked weights of one CLIPCondUNet.  ccn_forward / ccn_sample build (once per
+// shape and workspace address) a *plan*: the fixed list of kernel launches of one UNet evaluation with
+// every activation, GroupNorm partial-sum and scale/shift buffer placed in the caller's workspace.
+// ccn_sample replays the plan `steps` times -- conditioning (timestep MLP, z projection, all FiLM
+// linears) is hoisted in front of the loop for all steps, because t is batch-uniform and known ahead
+// (diffusion/ddim.py:25,32) -- either launch by launch or as one captured hipGraph.
+#include "../../include/ccn_hip.h"
+#include "ccn_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace ccn;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(CCN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+uint16_t f2bf_host(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct ParamInfo {
+    std::string name;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+struct ConvW {
+    int kind = KIND_C3S1;
+    int Cin = 0, Cout = 0, Cin_pad = 0, Cout_pad = 0, BN = 0, ntaps_w = 0;
+    void* w = nullptr;
+    float* bias = nullptr;
+};
+struct NormW { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
+struct ResW {
+    std::string prefix;
+    int C = 0;
+    NormW n1, n2;
+    ConvW c1, c2;
+    int film_off = 0;   // row offset into the concatenated FiLM linear: [off, off+C) scale, [off+C, off+2C) shift
+};
+enum LType { L_STEM, L_RES, L_DOWN, L_UP, L_HEAD };
+struct Layer { LType type; std::string name; int idx; };
+
+struct TensorRef {
+    void* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    float2* part = nullptr;      // GroupNorm partial sums written by the producer
+    int n_sp = 0, n_nt = 0, bn = 0;
+};
+
+struct StepCtx {
+    int step = 0;
+    const float* x_in = nullptr;   // NCHW fp32 image entering the stem
+    float* x_state = nullptr;      // DDIM state updated by the head (== x_in inside the loop)
+    float* eps_out = nullptr;
+    int do_ddim = 0;
+    float c[4] = {0, 0, 0, 0};
+};
+
+struct Launch {
+    int family;
+    double flops, bytes;
+    std::function<hipError_t(hipStream_t, const StepCtx&)> fn;
+};
+
+const char* kFamilies[] = {"conv3x3_s1_igemm", "conv3x3_s2_igemm", "convT4x4_s2_igemm", "stem_conv_igemm",
+                           "head_conv_ddim", "gn_finalize", "conditioning", "layout"};
+enum { F_C3S1 = 0, F_C3S2, F_CT4, F_STEM, F_HEAD, F_GNF, F_COND, F_LAYOUT, F_COUNT };
+
+struct Bump {
+    char* base; size_t off = 0; bool measure;
+    Bump(void* b, bool m) : base((char*)b), measure(m) {}
+    void* take(size_t bytes) { off = align_up(off, 256); void* p = measure ? nullptr : base + off; off += bytes; return p; }
+};
+
+struct GraphEntry {
+    int steps = 0;
+    std::vector<int32_t> ts;
+    std::vector<float> coef;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct Plan {
+    int B = 0, H = 0, W = 0, steps = 0;
+    void* ws = nullptr;
+    size_t bytes = 0;
+    // conditioning buffers
+    int32_t* ts_dev = nullptr;
+    float *temb = nullptr, *t1 = nullptr, *tp = nullptr, *zp = nullptr, *film = nullptr;
+    float *zbuf = nullptr, *xstate = nullptr;
+    std::vector<int32_t> ts_keep;        // host copy of the last timestep table (source of the async upload)
+    std::vector<Launch> ops;             // one UNet evaluation (+ DDIM update in the head)
+    std::map<std::string, TensorRef> named;
+    std::vector<GraphEntry> graphs;
+    ~Plan() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+    }
+};
+
+}  // namespace
+
+struct ccn_handle_s {
+    ccn_config_t cfg{};
+    int elem = 4;                       // bytes per activation / weight element
+    std::vector<ParamInfo> params;
+    std::map<std::string, std::vector<float>> host;   // loaded fp32 copies until commit
+    bool committed = false;
+    std::vector<void*> dev_allocs;
+    // model
+    ConvW stem, head;
+    NormW out_norm;
+    std::vector<ResW> res;
+    std::vector<ConvW> downs, ups;
+    std::vector<Layer> layers;
+    float *tp0_w = nullptr, *tp0_b = nullptr, *tp2_w = nullptr, *tp2_b = nullptr, *zp_w = nullptr, *zp_b = nullptr;
+    float *film_w = nullptr, *film_b = nullptr;
+    int F = 0;                          // rows of the concatenated FiLM linear
+    int G = 8;
+    std::vector<std::unique_ptr<Plan>> plans;
+    hipStream_t cap_stream = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Rec { int family; double flops, bytes; int e0, e1; };
+    std::vector<Rec> recs;
+    size_t ev_used = 0;
+    std::vector<std::string> fam_names;
+};
+
+namespace {
+
+// ---- architecture -> parameter list (models/unet.py:45-79 registration order) -------------------------
+void add_res_params(std::vector<ParamInfo>& v, const std::string& p, int c, int d)
+{
+    v.push_back({p + ".norm1.weight", {c}}); v.push_back({p + ".norm1.bias", {c}});
+    v.push_back({p + ".conv1.weight", {c, c, 3, 3}}); v.push_back({p + ".conv1.bias", {c}});
+    v.push_back({p + ".norm2.weight", {c}}); v.push_back({p + ".norm2.bias", {c}});
+    v.push_back({p + ".conv2.weight", {c, c, 3, 3}}); v.push_back({p + ".conv2.bias", {c}});
+    v.push_back({p + ".film.to_scale.weight", {c, d}}); v.push_back({p + ".film.to_scale.bias", {c}});
+    v.push_back({p + ".film.to_shift.weight", {c, d}}); v.push_back({p + ".film.to_shift.bias", {c}});
+}
+
+void build_arch(ccn_handle_s* h)
+{
+    const ccn_config_t& c = h->cfg;
+    auto& v = h->params;
+    const int td = c.time_dim;
+    v.push_back({"time_proj.0.weight", {td * 4, td}}); v.push_back({"time_proj.0.bias", {td * 4}});
+    v.push_back({"time_proj.2.weight", {td, td * 4}}); v.push_back({"time_proj.2.bias", {td}});
+    v.push_back({"z_proj.0.weight", {td, c.z_dim}}); v.push_back({"z_proj.0.bias", {td}});
+    v.push_back({"in_conv.weight", {c.base, c.img_ch, 3, 3}}); v.push_back({"in_conv.bias", {c.base}});
+    h->layers.push_back({L_STEM, "in_conv", 0});
+    int ch = c.base, film_off = 0;
+    auto add_res = [&](const std::string& name, int cc) {
+        add_res_params(v, name, cc, td);
+        ResW r; r.prefix = name; r.C = cc; r.film_off = film_off; film_off += 2 * cc;
+        h->res.push_back(r);
+        h->layers.push_back({L_RES, name, (int)h->res.size() - 1});
+    };
+    for (int i = 0; i < c.n_mult; ++i) {
+        const int m = c.ch_mult[i];
+        add_res("down." + std::to_string(3 * i), ch);
+        add_res("down." + std::to_string(3 * i + 1), ch);
+        const std::string dn = "down." + std::to_string(3 * i + 2);
+        v.push_back({dn + ".weight", {ch * m, ch, 3, 3}}); v.push_back({dn + ".bias", {ch * m}});
+        ConvW d; d.kind = KIND_C3S2; d.Cin = ch; d.Cout = ch * m; h->downs.push_back(d);
+        h->layers.push_back({L_DOWN, dn, i});
+        ch *= m;
+    }
+    add_res("mid1", ch);
+    add_res("mid2", ch);
+    for (int i = 0; i < c.n_mult; ++i) {
+        const int m = c.ch_mult[c.n_mult - 1 - i];
+        add_res("up." + std::to_string(3 * i), ch);
+        add_res("up." + std::to_string(3 * i + 1), ch);
+        const std::string un = "up." + std::to_string(3 * i + 2);
+        v.push_back({un + ".weight", {ch, ch / m, 4, 4}}); v.push_back({un + ".bias", {ch / m}});
+        ConvW u; u.kind = KIND_CT4; u.Cin = ch; u.Cout = ch / m; h->ups.push_back(u);
+        h->layers.push_back({L_UP, un, i});
+        ch /= m;
+    }
+    v.push_back({"out_norm.weight", {ch}}); v.push_back({"out_norm.bias", {ch}});
+    v.push_back({"out.weight", {c.img_ch, ch, 3, 3}}); v.push_back({"out.bias", {c.img_ch}});
+    h->layers.push_back({L_HEAD, "out", 0});
+    h->F = film_off;
+}
+
+// ---- weight repacking ------------------------------------------------------------------------------------
+int upload(ccn_handle_s* h, const void* src, size_t bytes, void** dst)
+{
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes ? bytes : 4));
+    h->dev_allocs.push_back(p);
+    if (bytes) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return CCN_OK;
+}
+int upload_f32(ccn_handle_s* h, const std::string& name, float** dst)
+{
+    const auto& v = h->host.at(name);
+    return upload(h, v.data(), v.size() * 4, (void**)dst);
+}
+
+// element (tap, o, i) of the packed [taps][Cout_pad][Cin_pad] tensor
+template <typename F>
+int pack_and_upload(ccn_handle_s* h, ConvW& cw, int taps, F&& at)
+{
+    const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+    cw.BN = conv_bn_for(cw.Cout, cw.kind);
+    cw.Cout_pad = (int)align_up(cw.Cout, cw.BN);
+    cw.ntaps_w = taps;
+    const size_t n = (size_t)taps * cw.Cout_pad * cw.Cin_pad;
+    (void)cke;
+    if (h->cfg.dtype == CCN_DTYPE_BF16) {
+        std::vector<uint16_t> buf(n, 0);
+        for (int t = 0; t < taps; ++t)
+            for (int o = 0; o < cw.Cout; ++o)
+                for (int i = 0; i < cw.Cin_pad; ++i) buf[((size_t)t * cw.Cout_pad + o) * cw.Cin_pad + i] = f2bf_host(at(t, o, i));
+        return upload(h, buf.data(), n * 2, &cw.w);
+    }
+    std::vector<float> buf(n, 0.f);
+    for (int t = 0; t < taps; ++t)
+        for (int o = 0; o < cw.Cout; ++o)
+            for (int i = 0; i < cw.Cin_pad; ++i) buf[((size_t)t * cw.Cout_pad + o) * cw.Cin_pad + i] = at(t, o, i);
+    return upload(h, buf.data(), n * 4, &cw.w);
+}
+
+int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2d weight (O, I, 3, 3)
+{
+    const float* w = h->host.at(name + ".weight").data();
+    const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+    cw.Cin_pad = (int)align_up(cw.Cin, cke);
+    const int I = cw.Cin;
+    int rc = pack_and_upload(h, cw, 9, [&](int t, int o, int i) { return i < I ? w[((size_t)o * I + i) * 9 + t] : 0.f; });
+    if (rc) return rc;
+    return upload_f32(h, name + ".bias", &cw.bias);
+}
+int pack_convT(ccn_handle_s* h, ConvW& cw, const std::string& name)     // ConvTranspose2d weight (I, O, 4, 4)
+{
+    const float* w = h->host.at(name + ".weight").data();
+    const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+    cw.Cin_pad = (int)align_up(cw.Cin, cke);
+    const int I = cw.Cin, O = cw.Cout;
+    int rc = pack_and_upload(h, cw, 16, [&](int t, int o, int i) { return i < I ? w[((size_t)i * O + o) * 16 + t] : 0.f; });
+    if (rc) return rc;
+    return upload_f32(h, name + ".bias", &cw.bias);
+}
+int pack_stem(ccn_handle_s* h, ConvW& cw, const std::string& name)      // Conv2d weight (O, img_ch, 3, 3) as K = I*9
+{
+    const float* w = h->host.at(name + ".weight").data();
+    const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+    cw.Cin_pad = cke;
+    const int K = cw.Cin * 9;
+    int rc = pack_and_upload(h, cw, 1, [&](int, int o, int k) { return k < K ? w[(size_t)o * K + k] : 0.f; });
+    if (rc) return rc;
+    return upload_f32(h, name + ".bias", &cw.bias);
+}
+
+// ---- plan -------------------------------------------------------------------------------------------------
+struct ConvGeom { int Hout, Wout, MH, MW, OS, npar, ntaps, n_ty, n_tx, n_nt; };
+
+ConvGeom conv_geom(const ConvW& cw, int Hin, int Win)
+{
+    ConvGeom g{};
+    switch (cw.kind) {
+        case KIND_C3S2: g.Hout = (Hin - 1) / 2 + 1; g.Wout = (Win - 1) / 2 + 1; g.MH = g.Hout; g.MW = g.Wout; g.OS = 1; g.npar = 1; g.ntaps = 9; break;
+        case KIND_CT4: g.Hout = Hin * 2; g.Wout = Win * 2; g.MH = Hin; g.MW = Win; g.OS = 2; g.npar = 4; g.ntaps = 4; break;
+        case KIND_STEM: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 1; break;
+        default: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 9; break;
+    }
+    g.n_ty = ceil_div(g.MH, 4); g.n_tx = ceil_div(g.MW, 32); g.n_nt = cw.Cout_pad / cw.BN;
+    return g;
+}
+
+void fill_taps(ConvArgs& a, int kind)
+{
+    std::memset(a.tapinfo, 0, sizeof(a.tapinfo));
+    if (kind == KIND_STEM) { a.tapinfo[0] = ConvArgs::make_tap(0, 0, 0); return; }
+    if (kind == KIND_CT4) {
+        // out = 2*in - 1 + k  (ConvTranspose2d k=4, s=2, p=1): even out <- k in {1 (d=0), 3 (d=-1)}; odd out <- k in {0 (d=+1), 2 (d=0)}
+        static const int kk[2][2] = {{1, 3}, {0, 2}}, dd[2][2] = {{0, -1}, {1, 0}};
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        a.tapinfo[(py * 2 + px) * 4 + i * 2 + j] = ConvArgs::make_tap(dd[py][i], dd[px][j], kk[py][i] * 4 + kk[px][j]);
+        return;
+    }
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) a.tapinfo[ky * 3 + kx] = ConvArgs::make_tap(ky - 1, kx - 1, ky * 3 + kx);
+}
+
+struct PlanBuilder {
+    ccn_handle_s* h;
+    Plan* plan;
+    Bump bump;
+    int B;
+    int film_stride;     // floats between consecutive samples' FiLM rows
+    PlanBuilder(ccn_handle_s* h_, Plan* p, void* ws, bool measure) : h(h_), plan(p), bump(ws, measure), B(p->B), film_stride(h_->F) {}
+
+    TensorRef new_tensor(int C, int H, int W)
+    {
+        TensorRef t; t.C = C; t.H = H; t.W = W;
+        t.p = bump.take((size_t)B * H * W * C * h->elem);
+        return t;
+    }
+    float2* new_ab(int C) { return (float2*)bump.take((size_t)B * C * sizeof(float2)); }
+    int groups_for(int C) const { return C < h->G ? C : h->G; }
+
+    // conv launch; `want_part`: also emit the partial sums of the output's GroupNorm
+    void conv(const ConvW& cw, int family, const TensorRef& in, TensorRef& out, const float2* gn_ab, int film_off,
+              const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
+    {
+        const ConvGeom g = conv_geom(cw, in.H, in.W);
+        ConvArgs a{};
+        a.in = in.p; a.w = cw.w; a.bias = cw.bias; a.out = out.p;
+        a.gn_ab = gn_ab; a.film = nullptr; a.res = res ? res->p : nullptr;
+        a.B = B; a.Hin = in.H; a.Win = in.W; a.Cin = cw.Cin; a.Cin_pad = cw.Cin_pad;
+        a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = cw.Cout; a.Cout_pad = cw.Cout_pad;
+        a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
+        a.n_ty = g.n_ty; a.n_tx = g.n_tx; a.n_nt = g.n_nt;
+        const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+        a.nchunk = cw.Cin_pad / cke;
+        a.silu = 1;
+        a.G = groups_for(cw.Cout); a.cpg = cw.Cout / a.G;
+        a.nslot = g.n_ty * g.n_tx * g.npar * g.n_nt;
+        a.film_bstride = film_stride;
+        fill_taps(a, cw.kind);
+        if (want_part) {
+            out.part = (float2*)bump.take((size_t)B * a.G * a.nslot * sizeof(float2));
+            out.n_sp = g.n_ty * g.n_tx * g.npar; out.n_nt = g.n_nt; out.bn = cw.BN;
+        }
+        a.part = out.part;
+        const double macs = (double)B * g.Hout * g.Wout * cw.Cout * (double)(cw.kind == KIND_CT4 ? 4 : (cw.kind == KIND_STEM ? 9 : 9)) * cw.Cin;
+        double bytes = ((double)B * in.H * in.W * cw.Cin + (double)B * g.Hout * g.Wout * cw.Cout + (res ? (double)B * g.Hout * g.Wout * cw.Cout : 0.0)
+                        + (double)(cw.kind == KIND_CT4 ? 16 : 9) * cw.Cin * cw.Cout) * h->elem;
+        if (is_stem) bytes = (double)B * in.H * in.W * cw.Cin * 4 + ((double)B * g.Hout * g.Wout * cw.Cout + 9.0 * cw.Cin * cw.Cout) * h->elem;
+        if (is_head) bytes = ((double)B * in.H * in.W * cw.Cin + 9.0 * cw.Cin * cw.Cout) * h->elem + 3.0 * (double)B * g.Hout * g.Wout * cw.Cout * 4;
+        const int dtype = h->cfg.dtype, kind = cw.kind, bn = cw.BN;
+        float* film_tab = plan->film;
+        const int F = film_stride;
+        const int Bc = B;
+        Launch L{family, 2.0 * macs, bytes, nullptr};
+        L.fn = [=](hipStream_t s, const StepCtx& c) -> hipError_t {
+            ConvArgs k = a;
+            if (film_off >= 0) k.film = film_tab + (size_t)c.step * Bc * F + film_off;
+            if (is_stem) k.in = c.x_in;
+            if (is_head) {
+                k.x_state = c.x_state; k.eps_out = c.eps_out; k.do_ddim = c.do_ddim;
+                k.c0 = c.c[0]; k.c1 = c.c[1]; k.c2 = c.c[2]; k.c3 = c.c[3];
+            }
+            return launch_conv(dtype, kind, bn, k, s);
+        };
+        plan->ops.push_back(std::move(L));
+    }
+
+    // GroupNorm finalize of tensor `t` for the norm (gamma, beta): returns the scale/shift table
+    const float2* gn(const TensorRef& t, const NormW& n)
+    {
+        float2* ab = new_ab(t.C);
+        const int G = groups_for(t.C), cpg = t.C / G;
+        const double count = (double)cpg * t.H * t.W;
+        const float2* part = t.part; const int n_sp = t.n_sp, n_nt = t.n_nt, bn = t.bn, C = t.C, Bc = B;
+        const float* gamma = n.gamma; const float* beta = n.beta;
+        Launch L{F_GNF, 0.0, (double)B * G * n_sp * n_nt * 8.0 + (double)B * C * 8.0, nullptr};
+        L.fn = [=](hipStream_t s, const StepCtx&) -> hipError_t {
+            return launch_gn_finalize(part, Bc, G, n_sp, n_nt, bn, cpg, C, count, gamma, beta, 1e-5f, ab, s);
+        };
+        plan->ops.push_back(std::move(L));
+        return ab;
+    }
+
+    // x + conv2(SiLU(GN2(FiLM(conv1(SiLU(GN1(x))))))) -- models/blocks.py:40-44
+    TensorRef resblock(const ResW& r, const TensorRef& x, bool out_feeds_gn, int film_off = -2)
+    {
+        const float2* ab1 = gn(x, r.n1);
+        TensorRef y = new_tensor(r.C, x.H, x.W);
+        conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
+        plan->named[r.prefix + ".film"] = y;
+        const float2* ab2 = gn(y, r.n2);
+        TensorRef o = new_tensor(r.C, x.H, x.W);
+        conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
+        plan->named[r.prefix] = o;
+        return o;
+    }
+};
+
+int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
+{
+    const ccn_config_t& c = h->cfg;
+    PlanBuilder pb(h, plan, ws, measure);
+    const int B = plan->B, H = plan->H, W = plan->W, S = plan->steps;
+    const int TR = B > S ? B : S, FR = S * B > B ? S * B : B;
+    plan->ts_dev = (int32_t*)pb.bump.take((size_t)S * 4);
+    plan->temb = (float*)pb.bump.take((size_t)TR * c.time_dim * 4);
+    plan->t1 = (float*)pb.bump.take((size_t)TR * c.time_dim * 4 * 4);
+    plan->tp = (float*)pb.bump.take((size_t)TR * c.time_dim * 4);
+    plan->zp = (float*)pb.bump.take((size_t)B * c.time_dim * 4);
+    plan->film = (float*)pb.bump.take((size_t)FR * h->F * 4);
+    plan->zbuf = (float*)pb.bump.take((size_t)B * c.z_dim * 4);
+    plan->xstate = (float*)pb.bump.take((size_t)B * c.img_ch * H * W * 4);
+
+    plan->ops.clear(); plan->named.clear();
+    TensorRef img; img.C = c.img_ch; img.H = H; img.W = W;     // NCHW fp32, pointer supplied per call
+    TensorRef x;
+    std::vector<TensorRef> skips;
+    const size_t nl = h->layers.size();
+    for (size_t li = 0; li < nl; ++li) {
+        const Layer& L = h->layers[li];
+        const bool next_is_gn = li + 1 < nl && (h->layers[li + 1].type == L_RES || h->layers[li + 1].type == L_HEAD);
+        switch (L.type) {
+            case L_STEM: {
+                x = pb.new_tensor(h->stem.Cout, H, W);
+                pb.conv(h->stem, F_STEM, img, x, nullptr, -1, nullptr, next_is_gn, true, false);
+                plan->named[L.name] = x;
+                break;
+            }
+            case L_RES: {
+                x = pb.resblock(h->res[L.idx], x, next_is_gn);
+                break;
+            }
+            case L_DOWN: {
+                skips.push_back(x);
+                const ConvW& cw = h->downs[L.idx];
+                if ((x.H % 2) || (x.W % 2)) return fail(CCN_EINVAL, "H and W must be divisible by 2^len(ch_mult)");
+                TensorRef o = pb.new_tensor(cw.Cout, x.H / 2, x.W / 2);
+                pb.conv(cw, F_C3S2, x, o, nullptr, -1, nullptr, next_is_gn);
+                plan->named[L.name] = o;
+                x = o;
+                break;
+            }
+            case L_UP: {
+                const ConvW& cw = h->ups[L.idx];
+                TensorRef o = pb.new_tensor(cw.Cout, x.H * 2, x.W * 2);
+                TensorRef sk = skips.back(); skips.pop_back();
+                if (sk.C != cw.Cout || sk.H != o.H || sk.W != o.W) return fail(CCN_EINVAL, "skip shape mismatch");
+                pb.conv(cw, F_CT4, x, o, nullptr, -1, &sk, next_is_gn);
+                plan->named[L.name] = o;
+                x = o;
+                break;
+            }
+            case L_HEAD: {
+                const float2* ab = pb.gn(x, h->out_norm);
+                TensorRef none;
+                pb.conv(h->head, F_HEAD, x, none, ab, -1, nullptr, false, false, true);
+                break;
+            }
+        }
+    }
+    plan->bytes = align_up(pb.bump.off, 256);
+    return CCN_OK;
+}
+
+int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t ws_bytes, Plan** out)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || steps <= 0) return fail(CCN_EINVAL, "B, H, W, steps must be positive");
+    const int div = 1 << h->cfg.n_mult;
+    if (H % div || W % div) return fail(CCN_EINVAL, "H and W must be divisible by 2^len(ch_mult)");
+    if (!ws || ((uintptr_t)ws & 255)) return fail(CCN_EWORKSPACE, "workspace must be non-null and 256-byte aligned");
+    for (auto& p : h->plans)
+        if (p->B == B && p->H == H && p->W == W && p->steps == steps && p->ws == ws) {
+            if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small");
+            *out = p.get();
+            return CCN_OK;
+        }
+    std::unique_ptr<Plan> p(new Plan);
+    p->B = B; p->H = H; p->W = W; p->steps = steps; p->ws = ws;
+    int rc = build_plan(h, p.get(), ws, false);
+    if (rc) return rc;
+    if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(p->bytes));
+    if (h->plans.size() >= 8) h->plans.erase(h->plans.begin());
+    *out = p.get();
+    h->plans.push_back(std::move(p));
+    return CCN_OK;
+}
+
+// ---- running a plan -------------------------------------------------------------------------------------------
+int ensure_events(ccn_handle_s* h, size_t n)
+{
+    while (h->ev_pool.size() < n) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    return CCN_OK;
+}
+
+int run_launch(ccn_handle_s* h, const Launch& L, hipStream_t s, const StepCtx& c)
+{
+    if (h->profiling) {
+        int rc = ensure_events(h, h->ev_used + 2);
+        if (rc) return rc;
+        const int e0 = (int)h->ev_used, e1 = e0 + 1;
+        h->ev_used += 2;
+        HIPCHK(hipEventRecord(h->ev_pool[e0], s));
+        HIPCHK(L.fn(s, c));
+        HIPCHK(hipEventRecord(h->ev_pool[e1], s));
+        h->recs.push_back({L.family, L.flops, L.bytes, e0, e1});
+        return CCN_OK;
+    }
+    HIPCHK(L.fn(s, c));
+    return CCN_OK;
+}
+
+// conditioning for `TR` time rows and `FR` FiLM rows; sample: FR = S*B rows (s,b); forward: FR = B rows
+int run_conditioning(ccn_handle_s* h, Plan* p, hipStream_t s, const int64_t* t_i64, int TR, int FR, int a_div)
+{
+    const ccn_config_t& c = h->cfg;
+    const int td = c.time_dim, B = p->B;
+    std::vector<Launch> v;
+    const float* z = p->zbuf;
+    v.push_back({F_COND, 0, 0, [=](hipStream_t st, const StepCtx&) {
+        return t_i64 ? launch_temb_i64(t_i64, p->temb, TR, td, st) : launch_temb_i32(p->ts_dev, p->temb, TR, td, st); }});
+    v.push_back({F_COND, 2.0 * TR * td * 4.0 * td, 0, [=](hipStream_t st, const StepCtx&) {
+        return launch_linear(p->temb, nullptr, 1, TR, h->tp0_w, h->tp0_b, p->t1, TR, td, 4 * td, 1, st); }});
+    v.push_back({F_COND, 2.0 * TR * td * 4.0 * td, 0, [=](hipStream_t st, const StepCtx&) {
+        return launch_linear(p->t1, nullptr, 1, TR, h->tp2_w, h->tp2_b, p->tp, TR, 4 * td, td, 0, st); }});
+    v.push_back({F_COND, 2.0 * B * c.z_dim * td, 0, [=](hipStream_t st, const StepCtx&) {
+        return launch_linear(z, nullptr, 1, B, h->zp_w, h->zp_b, p->zp, B, c.z_dim, td, 1, st); }});
+    v.push_back({F_COND, 2.0 * FR * td * (double)h->F, 0, [=](hipStream_t st, const StepCtx&) {
+        return launch_linear(p->tp, p->zp, a_div, B, h->film_w, h->film_b, p->film, FR, td, h->F, 0, st); }});
+    StepCtx c0;
+    for (auto& L : v) { int rc = run_launch(h, L, s, c0); if (rc) return rc; }
+    return CCN_OK;
+}
+
+int run_steps(ccn_handle_s* h, Plan* p, hipStream_t s, int steps, const float* coef)
+{
+    for (int i = 0; i < steps; ++i) {
+        StepCtx c;
+        c.step = i; c.x_in = p->xstate; c.x_state = p->xstate; c.eps_out = nullptr; c.do_ddim = 1;
+        for (int k = 0; k < 4; ++k) c.c[k] = coef[i * 4 + k];
+        for (auto& L : p->ops) { int rc = run_launch(h, L, s, c); if (rc) return rc; }
+    }
+    return CCN_OK;
+}
+
+int check_ready(ccn_handle_s* h)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    if (!h->committed) return fail(CCN_ESTATE, "ccn_commit_params has not succeeded on this handle");
+    return CCN_OK;
+}
+
+}  // namespace
+
+// =================================================================================================================
+extern "C" {
+
+const char* ccn_last_error(void) { return g_err.c_str(); }
+const char* ccn_version(void) { return "ccn_hip 0.1 (gfx950)"; }
+
+int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out)
+{
+    if (!cfg || !out) return fail(CCN_EINVAL, "null argument");
+    if (cfg->n_mult < 1 || cfg->n_mult > CCN_MAX_MULT) return fail(CCN_EINVAL, "n_mult out of range");
+    if (cfg->dtype != CCN_DTYPE_F32 && cfg->dtype != CCN_DTYPE_BF16) return fail(CCN_EINVAL, "unknown dtype");
+    if (cfg->base <= 0 || cfg->base % 8) return fail(CCN_EINVAL, "base must be a positive multiple of 8");
+    if (cfg->img_ch < 1 || cfg->img_ch * 9 > 32) return fail(CCN_EINVAL, "img_ch must be 1..3");
+    if (cfg->time_dim <= 0 || cfg->z_dim <= 0 || cfg->groups <= 0) return fail(CCN_EINVAL, "bad dims");
+    int ch = cfg->base;
+    for (int i = 0; i < cfg->n_mult; ++i) {
+        if (cfg->ch_mult[i] < 1) return fail(CCN_EINVAL, "ch_mult entries must be >= 1");
+        ch *= cfg->ch_mult[i];
+    }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(CCN_EHIP, "no HIP device");
+    std::unique_ptr<ccn_handle_s> h(new ccn_handle_s);
+    h->cfg = *cfg;
+    h->elem = cfg->dtype == CCN_DTYPE_BF16 ? 2 : 4;
+    h->G = cfg->groups;
+    build_arch(h.get());
+    for (auto& r : h->res)
+        if (r.C % (r.C < h->G ? r.C : h->G)) return fail(CCN_EINVAL, "channel count not divisible by GroupNorm groups");
+    HIPCHK(conv_prepare());
+    HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    for (int i = 0; i < F_COUNT; ++i) h->fam_names.push_back(kFamilies[i]);
+    *out = h.release();
+    return CCN_OK;
+}
+
+int ccn_destroy(ccn_handle_t h)
+{
+    if (!h) return CCN_OK;
+    (void)hipDeviceSynchronize();
+    h->plans.clear();
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+    return CCN_OK;
+}
+
+int ccn_num_params(ccn_handle_t h, int32_t* n)
+{
+    if (!h || !n) return fail(CCN_EINVAL, "null argument");
+    *n = (int32_t)h->params.size();
+    return CCN_OK;
+}
+
+int ccn_param_info(ccn_handle_t h, int32_t i, const char** name, int64_t shape[4], int32_t* ndim)
+{
+    if (!h || !name || !shape || !ndim) return fail(CCN_EINVAL, "null argument");
+    if (i < 0 || i >= (int32_t)h->params.size()) return fail(CCN_EINVAL, "parameter index out of range");
+    const ParamInfo& p = h->params[i];
+    *name = p.name.c_str();
+    *ndim = (int32_t)p.shape.size();
+    for (size_t k = 0; k < 4; ++k) shape[k] = k < p.shape.size() ? p.shape[k] : 1;
+    return CCN_OK;
+}
+
+int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const int64_t* shape, int32_t ndim)
+{
+    if (!h || !name || !data || !shape) return fail(CCN_EINVAL, "null argument");
+    const ParamInfo* pi = nullptr;
+    for (auto& p : h->params) if (p.name == name) { pi = &p; break; }
+    if (!pi) return fail(CCN_EWEIGHTS, std::string("Unexpected key in state_dict: ") + name);
+    if ((size_t)ndim != pi->shape.size()) return fail(CCN_EWEIGHTS, std::string("size mismatch for ") + name);
+    for (int k = 0; k < ndim; ++k)
+        if (shape[k] != pi->shape[k]) return fail(CCN_EWEIGHTS, std::string("size mismatch for ") + name);
+    std::vector<float> buf(pi->numel());
+    hipPointerAttribute_t attr;
+    const hipError_t pe = hipPointerGetAttributes(&attr, data);
+    if (pe == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        HIPCHK(hipMemcpy(buf.data(), data, buf.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        (void)hipGetLastError();
+        std::memcpy(buf.data(), data, buf.size() * 4);
+    }
+    h->host[name] = std::move(buf);
+    h->committed = false;
+    return CCN_OK;
+}
+
+int ccn_commit_params(ccn_handle_t h)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    std::string missing;
+    for (auto& p : h->params)
+        if (!h->host.count(p.name)) missing += (missing.empty() ? "" : ", ") + p.name;
+    if (!missing.empty()) return fail(CCN_EWEIGHTS, "Missing key(s) in state_dict: " + missing);
+    h->plans.clear();
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    h->dev_allocs.clear();
+    const ccn_config_t& c = h->cfg;
+    int rc;
+    h->stem = ConvW(); h->stem.kind = KIND_STEM; h->stem.Cin = c.img_ch; h->stem.Cout = c.base;
+    if ((rc = pack_stem(h, h->stem, "in_conv"))) return rc;
+    for (auto& r : h->res) {
+        r.c1 = ConvW(); r.c1.kind = KIND_C3S1; r.c1.Cin = r.C; r.c1.Cout = r.C;
+        r.c2 = r.c1;
+        if ((rc = pack_conv3(h, r.c1, r.prefix + ".conv1"))) return rc;
+        if ((rc = pack_conv3(h, r.c2, r.prefix + ".conv2"))) return rc;
+        r.n1.C = r.n2.C = r.C;
+        if ((rc = upload_f32(h, r.prefix + ".norm1.weight", &r.n1.gamma))) return rc;
+        if ((rc = upload_f32(h, r.prefix + ".norm1.bias", &r.n1.beta))) return rc;
+        if ((rc = upload_f32(h, r.prefix + ".norm2.weight", &r.n2.gamma))) return rc;
+        if ((rc = upload_f32(h, r.prefix + ".norm2.bias", &r.n2.beta))) return rc;
+    }
+    for (size_t i = 0; i < h->downs.size(); ++i)
+        if ((rc = pack_conv3(h, h->downs[i], "down." + std::to_string(3 * i + 2)))) return rc;
+    for (size_t i = 0; i < h->ups.size(); ++i)
+        if ((rc = pack_convT(h, h->ups[i], "up." + std::to_string(3 * i + 2)))) return rc;
+    h->head = ConvW(); h->head.kind = KIND_HEAD; h->head.Cin = c.base; h->head.Cout = c.img_ch;
+    if ((rc = pack_conv3(h, h->head, "out"))) return rc;
+    h->out_norm.C = c.base;
+    if ((rc = upload_f32(h, "out_norm.weight", &h->out_norm.gamma))) return rc;
+    if ((rc = upload_f32(h, "out_norm.bias", &h->out_norm.beta))) return rc;
+    if ((rc = upload_f32(h, "time_proj.0.weight", &h->tp0_w))) return rc;
+    if ((rc = upload_f32(h, "time_proj.0.bias", &h->tp0_b))) return rc;
+    if ((rc = upload_f32(h, "time_proj.2.weight", &h->tp2_w))) return rc;
+    if ((rc = upload_f32(h, "time_proj.2.bias", &h->tp2_b))) return rc;
+    if ((rc = upload_f32(h, "z_proj.0.weight", &h->zp_w))) return rc;
+    if ((rc = upload_f32(h, "z_proj.0.bias", &h->zp_b))) return rc;
+    // all FiLM linears as one (F x time_dim) matrix: per block [to_scale rows | to_shift rows]
+    std::vector<float> fw((size_t)h->F * c.time_dim), fb((size_t)h->F);
+    for (auto& r : h->res) {
+        const char* parts[2] = {".film.to_scale", ".film.to_shift"};
+        for (int q = 0; q < 2; ++q) {
+            const auto& w = h->host.at(r.prefix + parts[q] + ".weight");
+            const auto& b = h->host.at(r.prefix + parts[q] + ".bias");
+            std::memcpy(&fw[(size_t)(r.film_off + q * r.C) * c.time_dim], w.data(), w.size() * 4);
+            std::memcpy(&fb[(size_t)(r.film_off + q * r.C)], b.data(), b.size() * 4);
+        }
+    }
+    if ((rc = upload(h, fw.data(), fw.size() * 4, (void**)&h->film_w))) return rc;
+    if ((rc = upload(h, fb.data(), fb.size() * 4, (void**)&h->film_b))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    h->host.clear();
+    h->committed = true;
+    return CCN_OK;
+}
+
+int ccn_workspace_bytes(ccn_handle_t h, int32_t B, int32_t H, int32_t W, int32_t steps, size_t* bytes)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!bytes) return fail(CCN_EINVAL, "null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || steps <= 0) return fail(CCN_EINVAL, "B, H, W, steps must be positive");
+    const int div = 1 << h->cfg.n_mult;
+    if (H % div || W % div) return fail(CCN_EINVAL, "H and W must be divisible by 2^len(ch_mult)");
+    Plan p; p.B = B; p.H = H; p.W = W; p.steps = steps;
+    rc = build_plan(h, &p, nullptr, true);
+    if (rc) return rc;
+    *bytes = p.bytes;
+    return CCN_OK;
+}
+
+int ccn_forward(ccn_handle_t h, const float* x_dev, const float* z_dev, const int64_t* t_dev, float* eps_dev,
+                int32_t B, int32_t H, int32_t W, void* workspace_dev, size_t workspace_bytes, void* stream)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!x_dev || !z_dev || !t_dev || !eps_dev) return fail(CCN_EINVAL, "null tensor pointer");
+    Plan* p = nullptr;
+    if ((rc = get_plan(h, B, H, W, 1, workspace_dev, workspace_bytes, &p))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(p->zbuf, z_dev, (size_t)B * h->cfg.z_dim * 4, hipMemcpyDeviceToDevice, s));
+    if ((rc = run_conditioning(h, p, s, t_dev, B, B, 1))) return rc;
+    StepCtx c;
+    c.step = 0; c.x_in = x_dev; c.x_state = nullptr; c.eps_out = eps_dev; c.do_ddim = 0;
+    for (auto& L : p->ops) if ((rc = run_launch(h, L, s, c))) return rc;
+    return CCN_OK;
+}
+
+int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev, int32_t B, int32_t H, int32_t W,
+               int32_t steps, const int32_t* ts_host, const float* coef_host, void* workspace_dev, size_t workspace_bytes,
+               void* stream, int32_t use_graph)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!z_dev || !x_T_dev || !x_out_dev || !ts_host || !coef_host) return fail(CCN_EINVAL, "null pointer");
+    Plan* p = nullptr;
+    if ((rc = get_plan(h, B, H, W, steps, workspace_dev, workspace_bytes, &p))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t img_bytes = (size_t)B * h->cfg.img_ch * H * W * 4;
+    HIPCHK(hipMemcpyAsync(p->zbuf, z_dev, (size_t)B * h->cfg.z_dim * 4, hipMemcpyDeviceToDevice, s));
+    if (x_T_dev != p->xstate) HIPCHK(hipMemcpyAsync(p->xstate, x_T_dev, img_bytes, hipMemcpyDeviceToDevice, s));
+
+    p->ts_keep.assign(ts_host, ts_host + steps);
+    HIPCHK(hipMemcpyAsync(p->ts_dev, p->ts_keep.data(), (size_t)steps * 4, hipMemcpyHostToDevice, s));
+    if (use_graph && !h->profiling) {
+        GraphEntry* ge = nullptr;
+        for (auto& g : p->graphs)
+            if (g.steps == steps && !std::memcmp(g.ts.data(), ts_host, (size_t)steps * 4) &&
+                !std::memcmp(g.coef.data(), coef_host, (size_t)steps * 16)) { ge = &g; break; }
+        if (!ge) {
+            GraphEntry g;
+            g.steps = steps; g.ts.assign(ts_host, ts_host + steps); g.coef.assign(coef_host, coef_host + steps * 4);
+            HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
+            rc = run_conditioning(h, p, h->cap_stream, nullptr, steps, steps * B, B);
+            if (!rc) rc = run_steps(h, p, h->cap_stream, steps, coef_host);
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(CCN_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            g.graph = graph;
+            HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            p->graphs.push_back(g);
+            ge = &p->graphs.back();
+        }
+        HIPCHK(hipGraphLaunch(ge->exec, s));
+    } else {
+        if ((rc = run_conditioning(h, p, s, nullptr, steps, steps * B, B))) return rc;
+        if ((rc = run_steps(h, p, s, steps, coef_host))) return rc;
+    }
+    if (x_out_dev != p->xstate) HIPCHK(hipMemcpyAsync(x_out_dev, p->xstate, img_bytes, hipMemcpyDeviceToDevice, s));
+    return CCN_OK;
+}
+
+int ccn_ddim_step(float* x_dev, const float* eps_dev, const float* noise_dev, float c0, float c1, float c2, float c3,
+                  float sigma, int64_t n, void* stream)
+{
+    if (!x_dev || !eps_dev || n < 0) return fail(CCN_EINVAL, "bad argument");
+    if (n == 0) return CCN_OK;
+    HIPCHK(launch_ddim_step(x_dev, eps_dev, noise_dev, c0, c1, c2, c3, sigma, n, (hipStream_t)stream));
+    return CCN_OK;
+}
+
+int ccn_q_sample(float* out_dev, const float* x0_dev, const float* noise_dev, const float* a_dev, const float* s_dev,
+                 int32_t B, int64_t per_sample, void* stream)
+{
+    if (!out_dev || !x0_dev || !noise_dev || !a_dev || !s_dev || B <= 0 || per_sample <= 0) return fail(CCN_EINVAL, "bad argument");
+    HIPCHK(launch_q_sample(out_dev, x0_dev, noise_dev, a_dev, s_dev, B, per_sample, (hipStream_t)stream));
+    return CCN_OK;
+}
+
+int ccn_predict_x0(float* out_dev, const float* x_t_dev, const float* eps_dev, const float* a_dev, const float* s_dev,
+                   int32_t B, int64_t per_sample, void* stream)
+{
+    if (!out_dev || !x_t_dev || !eps_dev || !a_dev || !s_dev || B <= 0 || per_sample <= 0) return fail(CCN_EINVAL, "bad argument");
+    HIPCHK(launch_predict_x0(out_dev, x_t_dev, eps_dev, a_dev, s_dev, B, per_sample, (hipStream_t)stream));
+    return CCN_OK;
+}
+
+int ccn_timestep_embedding(const int64_t* t_dev, float* out_dev, int32_t n, int32_t dim, void* stream)
+{
+    if (!t_dev || !out_dev || n <= 0 || dim <= 0) return fail(CCN_EINVAL, "bad argument");
+    HIPCHK(launch_temb_i64(t_dev, out_dev, n, dim, (hipStream_t)stream));
+    return CCN_OK;
+}
+
+int ccn_film_forward(const float* x_dev, const float* h_dev, const float* ws_dev, const float* bs_dev, const float* wh_dev,
+                     const float* bh_dev, float* y_dev, int32_t B, int32_t C, int32_t H, int32_t W, int32_t D,
+                     float* scratch_dev, void* stream)
+{
+    if (!x_dev || !h_dev || !ws_dev || !bs_dev || !wh_dev || !bh_dev || !y_dev || !scratch_dev) return fail(CCN_EINVAL, "null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0) return fail(CCN_EINVAL, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* sc = scratch_dev; float* sh = scratch_dev + (size_t)B * C;
+    HIPCHK(launch_linear(h_dev, nullptr, 1, B, ws_dev, bs_dev, sc, B, D, C, 0, s));
+    HIPCHK(launch_linear(h_dev, nullptr, 1, B, wh_dev, bh_dev, sh, B, D, C, 0, s));
+    HIPCHK(launch_film_nchw(x_dev, sc, sh, y_dev, B, C, (int64_t)H * W, s));
+    return CCN_OK;
+}
+
+int ccn_resblock_forward(ccn_handle_t h, const char* prefix, const float* x_dev, const float* cond_dev, float* y_dev,
+                         int32_t B, int32_t H, int32_t W, void* workspace_dev, size_t workspace_bytes, void* stream)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!prefix || !x_dev || !cond_dev || !y_dev || !workspace_dev) return fail(CCN_EINVAL, "null pointer");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(CCN_EINVAL, "bad shape");
+    const ResW* r = nullptr;
+    for (auto& q : h->res) if (q.prefix == prefix) { r = &q; break; }
+    if (!r) return fail(CCN_EINVAL, std::string("no ResBlock with prefix ") + prefix);
+    if ((uintptr_t)workspace_dev & 255) return fail(CCN_EWORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Plan tmp; tmp.B = B; tmp.H = H; tmp.W = W; tmp.steps = 1;
+    PlanBuilder pb(h, &tmp, workspace_dev, false);
+    pb.film_stride = 2 * r->C;                                    // dense (B, 2C) table: [scale | shift] of this block only
+    tmp.film = (float*)pb.bump.take((size_t)B * 2 * r->C * 4);
+    TensorRef x = pb.new_tensor(r->C, H, W);
+    const int G = pb.groups_for(r->C), cpg = r->C / G;
+    int nslot = (H * W + 1023) / 1024; if (nslot < 1) nslot = 1;
+    x.part = (float2*)pb.bump.take((size_t)B * G * nslot * sizeof(float2));
+    x.n_sp = nslot; x.n_nt = 1; x.bn = 1 << 30;
+    TensorRef o = pb.resblock(*r, x, false, 0);
+    if (pb.bump.off > workspace_bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(pb.bump.off));
+    HIPCHK(launch_nchw_to_nhwc(h->cfg.dtype, x_dev, x.p, B, r->C, H, W, s));
+    HIPCHK(launch_gn_partials(h->cfg.dtype, x.p, x.part, B, H * W, r->C, cpg, G, nslot, s));
+    HIPCHK(launch_linear(cond_dev, nullptr, 1, B, h->film_w + (size_t)r->film_off * h->cfg.time_dim, h->film_b + r->film_off,
+                         tmp.film, B, h->cfg.time_dim, 2 * r->C, 0, s));
+    StepCtx c;
+    for (auto& L : tmp.ops) HIPCHK(L.fn(s, c));
+    HIPCHK(launch_nhwc_to_nchw(h->cfg.dtype, o.p, y_dev, B, r->C, H, W, s));
+    return CCN_OK;
+}
+
+int ccn_read_activation(ccn_handle_t h, const char* name, float* out_dev, size_t out_elems, void* stream)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!name || !out_dev) return fail(CCN_EINVAL, "null pointer");
+    if (h->plans.empty()) return fail(CCN_ESTATE, "no forward has run yet");
+    Plan* p = h->plans.back().get();
+    auto it = p->named.find(name);
+    if (it == p->named.end()) return fail(CCN_EINVAL, std::string("unknown activation ") + name);
+    const TensorRef& t = it->second;
+    if (out_elems < (size_t)p->B * t.C * t.H * t.W) return fail(CCN_EINVAL, "output buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(launch_nhwc_to_nchw(h->cfg.dtype, t.p, out_dev, p->B, t.C, t.H, t.W, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CCN_OK;
+}
+
+int ccn_profile_enable(ccn_handle_t h, int32_t on)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    h->profiling = on != 0;
+    h->recs.clear();
+    h->ev_used = 0;
+    return CCN_OK;
+}
+
+int ccn_profile_read(ccn_handle_t h, const char** names, float* ms, int32_t* calls, double* flops, double* bytes,
+                     int32_t cap, int32_t* n)
+{
+    if (!h || !names || !ms || !calls || !flops || !bytes || !n) return fail(CCN_EINVAL, "null pointer");
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> t(F_COUNT, 0.0), fl(F_COUNT, 0.0), by(F_COUNT, 0.0);
+    std::vector<int> cnt(F_COUNT, 0);
+    for (auto& r : h->recs) {
+        float e = 0.f;
+        HIPCHK(hipEventElapsedTime(&e, h->ev_pool[r.e0], h->ev_pool[r.e1]));
+        t[r.family] += e; fl[r.family] += r.flops; by[r.family] += r.bytes; cnt[r.family]++;
+    }
+    int k = 0;
+    for (int f = 0; f < F_COUNT && k < cap; ++f) {
+        if (!cnt[f]) continue;
+        names[k] = h->fam_names[f].c_str(); ms[k] = (float)t[f]; calls[k] = cnt[f]; flops[k] = fl[f]; bytes[k] = by[f];
+        ++k;
+    }
+    *n = k;
+    h->recs.clear();
+    h->ev_used = 0;
+    return CCN_OK;
+}
+
+int ccn_algorithmic_work(ccn_handle_t h, int32_t B, int32_t H, int32_t W, double* flops, double* bytes)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!flops || !bytes) return fail(CCN_EINVAL, "null pointer");
+    Plan p; p.B = B; p.H = H; p.W = W; p.steps = 1;
+    if ((rc = build_plan(h, &p, nullptr, true))) return rc;
+    double f = 0, b = 0;
+    for (auto& L : p.ops) if (L.family <= F_HEAD) { f += L.flops; b += L.bytes; }
+    const ccn_config_t& c = h->cfg;
+    f += 2.0 * B * ((double)c.time_dim * 4 * c.time_dim * 2 + (double)c.z_dim * c.time_dim + (double)c.time_dim * h->F);
+    *flops = f; *bytes = b;
+    return CCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Internal declarations shared by the kernel file and the host API file of libccn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace ccn {
+
+// ---- implicit-GEMM convolution ------------------------------------------------------------------
+// One kernel family covers every contraction on the path (models/unet.py:55,63,75,79 and
+// models/blocks.py:34,36).  M-space = the pixel grid a block tiles (TH=4 x TW=32 pixels per block):
+//   3x3 s1  : M = output = input grid,         in = m + d,      out = m
+//   3x3 s2  : M = output grid,                 in = 2m + d,     out = m
+//   convT4  : M = input grid, 4 output parities, in = m + d,    out = 2m + parity   (2x2 taps each)
+//   stem    : im2col of the NCHW fp32 image (K = img_ch*9, one "tap")
+enum ConvKind { KIND_C3S1 = 0, KIND_C3S2 = 1, KIND_CT4 = 2, KIND_STEM = 3, KIND_HEAD = 4 };
+
+struct ConvArgs {
+    const void* in;         // NHWC T [B][Hin][Win][Cin]   (stem: NCHW fp32 [B][Cin][Hin][Win])
+    const void* w;          // packed [tap][Cout_pad][Cin_pad] T
+    const float* bias;      // [Cout]
+    void* out;              // NHWC T [B][Hout][Wout][Cout] (head: unused)
+    const float2* gn_ab;    // prologue GroupNorm as per-(b,channel) (scale, shift), or null
+    const float* film;      // epilogue FiLM for this step: [B][film_bstride], s at [n], shift at [Cout+n]; or null
+    const void* res;        // epilogue residual / skip, NHWC T like out; or null
+    float2* part;           // epilogue GroupNorm partial sums [B][G][nslot] (sum, sum of squares); or null
+    float* x_state;         // head: DDIM state, NCHW fp32, updated in place when do_ddim
+    float* eps_out;         // head: eps NCHW fp32, or null
+    float c0, c1, c2, c3;   // head: DDIM coefficients
+    int do_ddim;
+    int film_bstride;
+    int B, Hin, Win, Cin, Cin_pad, Hout, Wout, Cout, Cout_pad;
+    int MH, MW, OS, npar;
+    int n_ty, n_tx, n_nt, nchunk, ntaps;
+    int silu;               // SiLU after the prologue GroupNorm
+    int cpg, G, nslot;      // output GroupNorm geometry
+    // per tap: bits 0-1 = dy+1, bits 2-3 = dx+1, bits 4.. = weight tap index; convT: entry [parity*4 + tap]
+    int tapinfo[16];
+    __host__ __device__ int tapinfo_dy(int i) const { return (tapinfo[i] & 3) - 1; }
+    __host__ __device__ int tapinfo_dx(int i) const { return ((tapinfo[i] >> 2) & 3) - 1; }
+    __host__ __device__ int tapinfo_w(int i) const { return tapinfo[i] >> 4; }
+    static int make_tap(int dy, int dx, int wt) { return (dy + 1) | ((dx + 1) << 2) | (wt << 4); }
+};
+
+int conv_bn_for(int cout, int kind);                       // N-tile width used for a layer
+size_t conv_lds_bytes(int dtype, int kind, int bn);
+hipError_t conv_prepare();                                 // raise dynamic-LDS limits once
+hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream_t s);
+
+// ---- GroupNorm finalize: partial sums -> per-(b,channel) scale/shift --------------------------------
+hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C,
+                              double count, const float* gamma, const float* beta, float eps,
+                              float2* ab, hipStream_t s);
+
+// ---- conditioning (tiny GEMVs, fp32) --------------------------------------------------------------
+hipError_t launch_temb_i64(const int64_t* t, float* out, int n, int dim, hipStream_t s);
+hipError_t launch_temb_i32(const int32_t* t, float* out, int n, int dim, hipStream_t s);
+// y[r][n] = act(sum_k x[r][k] W[n][k] + b[n]);  x row r is xa[ra(r)] (+ xb[rb(r)] when xb != null) where
+// ra(r) = r / a_div, rb(r) = r % b_mod (a_div = 1, b_mod = R gives plain rows).
+hipError_t launch_linear(const float* xa, const float* xb, int a_div, int b_mod, const float* W, const float* b,
+                         float* y, int R, int K, int N, int act_silu, hipStream_t s);
+
+// ---- elementwise ---------------------------------------------------------------------------------
+hipError_t launch_ddim_step(float* x, const float* eps, const float* noise, float c0, float c1, float c2, float c3,
+                            float sigma, int64_t n, hipStream_t s);
+hipError_t launch_q_sample(float* out, const float* x0, const float* noise, const float* a, const float* sg,
+                           int B, int64_t per, hipStream_t s);
+hipError_t launch_predict_x0(float* out, const float* xt, const float* eps, const float* a, const float* sg,
+                             int B, int64_t per, hipStream_t s);
+hipError_t launch_film_nchw(const float* x, const float* sc, const float* sh, float* y, int B, int C, int64_t hw,
+                            hipStream_t s);
+hipError_t launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, hipStream_t s);
+// GroupNorm partial sums of an NHWC tensor that no conv epilogue produced (operator-level entry points)
+hipError_t launch_gn_partials(int dtype, const void* x, float2* part, int B, int HW, int C, int cpg, int G,
+                              int nslot, hipStream_t s);
+
+}  // namespace ccn

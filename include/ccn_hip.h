@@ -1,0 +1,162 @@
+/*
+ * ccn_hip.h -- C ABI of libccn_hip.so: the MI355X (gfx950) DDIM reconstruction path of
+ * clip-feature-codec (CLIPCondUNet epsilon-prediction forward + DDIM update).
+ *
+ * The reference (lionl1106/Clip-Neural-image-conpression) is pure Python on torch.nn and has no
+ * FFI of its own; every entry point below names the reference interface it stands in for
+ * (paths relative to src/clip_feature_codec/).  A reference maintainer binds them with ctypes
+ * (see INTEGRATION.md); nothing here carries a torch type.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a CCN_E* code otherwise; ccn_last_error() returns a
+ *     thread-local message for the last failure.  No C++ exception crosses the boundary.
+ *   - pointers named *_dev are device (HBM) pointers owned by the caller; *_host are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls enqueue work and return;
+ *     they never synchronise the device, except where stated.
+ *   - image tensors at the boundary are NCHW fp32 contiguous, exactly what the reference passes to
+ *     CLIPCondUNet.forward; NHWC and (in bf16 mode) bf16 are internal.
+ *   - one handle per process per device; handles are not thread-safe.
+ */
+#ifndef CCN_HIP_H
+#define CCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCN_OK            0
+#define CCN_EINVAL        1   /* bad argument / unsupported shape            */
+#define CCN_EHIP          2   /* a HIP runtime call failed                   */
+#define CCN_EWEIGHTS      3   /* missing / unexpected / mis-shaped parameter */
+#define CCN_EWORKSPACE    4   /* workspace too small or misaligned           */
+#define CCN_ESTATE        5   /* call order violated                         */
+
+#define CCN_DTYPE_F32     0   /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode        */
+#define CCN_DTYPE_BF16    1   /* bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate  */
+
+#define CCN_MAX_MULT      8
+
+typedef struct ccn_handle_s* ccn_handle_t;
+
+/* Constructor arguments of CLIPCondUNet (models/unet.py:45) plus the arithmetic mode. */
+typedef struct ccn_config {
+    int32_t z_dim;                 /* 512                                         */
+    int32_t base;                  /* 128                                         */
+    int32_t n_mult;                /* len(ch_mult)                                */
+    int32_t ch_mult[CCN_MAX_MULT]; /* (1,2,2); widths are a running product       */
+    int32_t time_dim;              /* 256                                         */
+    int32_t img_ch;                /* 3                                           */
+    int32_t groups;                /* GroupNorm groups, 8 (models/blocks.py:31)   */
+    int32_t dtype;                 /* CCN_DTYPE_*                                 */
+} ccn_config_t;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* CLIPCondUNet.__init__ + .to(device) (models/unet.py:45-79; cli/eval.py:50). Uses the current HIP device. */
+int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out);
+int ccn_destroy(ccn_handle_t h);
+
+/* Number of state-dict entries the handle expects, and the i-th key / shape: the key set of
+ * CLIPCondUNet.state_dict() (192 entries at base=128, ch_mult=(1,2,2)). */
+int ccn_num_params(ccn_handle_t h, int32_t* n);
+int ccn_param_info(ccn_handle_t h, int32_t i, const char** name, int64_t shape[4], int32_t* ndim);
+
+/* One entry of load_state_dict (cli/eval.py:51, cli/reconstruct_diffusion.py:48).  `data` is fp32,
+ * contiguous, in the reference's own layout (Conv2d OIHW, ConvTranspose2d (Cin,Cout,4,4), Linear
+ * (out,in)); host or device pointer.  The library copies; the caller keeps ownership. */
+int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+
+/* strict=True check (every key loaded exactly once with the right shape), then repack to the kernel
+ * layouts ([tap][Cout][Cin], bf16 copies in bf16 mode) and upload.  Synchronises the device. */
+int ccn_commit_params(ccn_handle_t h);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* Scratch needed by ccn_forward / ccn_sample for this shape; the caller allocates it (e.g. through
+ * torch's caching allocator), 256-byte aligned, and keeps it alive and at the same address while a
+ * captured graph for it is cached. `steps` = 1 for ccn_forward. */
+int ccn_workspace_bytes(ccn_handle_t h, int32_t B, int32_t H, int32_t W, int32_t steps, size_t* bytes);
+
+/* CLIPCondUNet.forward(x_t, z_clip, t) (models/unet.py:81-106).
+ * x_dev (B,img_ch,H,W) fp32 NCHW; z_dev (B,z_dim) fp32; t_dev (B,) int64; eps_dev (B,img_ch,H,W) fp32 NCHW. */
+int ccn_forward(ccn_handle_t h, const float* x_dev, const float* z_dev, const int64_t* t_dev,
+                float* eps_dev, int32_t B, int32_t H, int32_t W,
+                void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* DDIMSampler.sample(model, z_clip, shape, steps, x_T=...) for eta = 0 (diffusion/ddim.py:21-45).
+ * ts_host[steps]: the timestep table (linspace(T-1,0,steps).long());
+ * coef_host[steps][4]: fp32 (sqrt(1-ab_t), sqrt(ab_t), sqrt(ab_s), sqrt(ab_s - sigma^2)) per step, so that
+ *     x0 = clamp((x - c0*eps)/c1, -1, 1);  x = c2*x0 + c3*eps      -- every op rounded to fp32
+ * x_T_dev -> x_out_dev (may alias), (B,img_ch,H,W) fp32 NCHW, unclamped like the reference.
+ * use_graph != 0: the whole steps-long loop is captured once into a hipGraph (cached per
+ * shape/steps/table/workspace address) and replayed with one launch. */
+int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev,
+               int32_t B, int32_t H, int32_t W, int32_t steps,
+               const int32_t* ts_host, const float* coef_host,
+               void* workspace_dev, size_t workspace_bytes, void* stream, int32_t use_graph);
+
+/* One DDIM update outside the fused loop (eta > 0, or a caller-driven loop; diffusion/ddim.py:34-45):
+ * x = c2*clamp((x - c0*eps)/c1) + c3*eps [+ sigma*noise]; noise_dev may be NULL. In place on x_dev. */
+int ccn_ddim_step(float* x_dev, const float* eps_dev, const float* noise_dev,
+                  float c0, float c1, float c2, float c3, float sigma, int64_t n, void* stream);
+
+/* NoiseScheduler.q_sample (diffusion/scheduler.py:46-49): out[b] = a[b]*x0[b] + s[b]*noise[b];
+ * a_dev/s_dev are the gathered per-sample coefficients, (B,) fp32; per_sample = C*H*W. */
+int ccn_q_sample(float* out_dev, const float* x0_dev, const float* noise_dev,
+                 const float* a_dev, const float* s_dev, int32_t B, int64_t per_sample, void* stream);
+
+/* NoiseScheduler.predict_x0_from_eps (diffusion/scheduler.py:51-55): out[b] = (x_t[b] - s[b]*eps[b]) / a[b]. */
+int ccn_predict_x0(float* out_dev, const float* x_t_dev, const float* eps_dev,
+                   const float* a_dev, const float* s_dev, int32_t B, int64_t per_sample, void* stream);
+
+/* ---- operator-level entry points (what the reference's unit tests exercise) ------------------ */
+
+/* FiLM.forward (models/blocks.py:22-25) with explicit parameters: y = x*(1 + Ws h + bs) + (Wh h + bh).
+ * x/y (B,C,H,W) fp32 NCHW; h (B,D); Ws/Wh (C,D); bs/bh (C,). All device pointers.
+ * scratch_dev: at least 2*B*C floats. */
+int ccn_film_forward(const float* x_dev, const float* h_dev, const float* ws_dev, const float* bs_dev,
+                     const float* wh_dev, const float* bh_dev, float* y_dev,
+                     int32_t B, int32_t C, int32_t H, int32_t W, int32_t D,
+                     float* scratch_dev, void* stream);
+
+/* ResBlock.forward (models/blocks.py:40-44) of the block whose state-dict prefix is `prefix`
+ * ("down.0", "mid1", "up.4", ...), using the handle's committed weights and arithmetic mode.
+ * x/y (B,C,H,W) fp32 NCHW; h (B,time_dim) fp32.  Workspace: ccn_workspace_bytes(h,B,H,W,1) is enough
+ * for any block at resolution HxW. */
+int ccn_resblock_forward(ccn_handle_t h, const char* prefix, const float* x_dev, const float* cond_dev,
+                         float* y_dev, int32_t B, int32_t H, int32_t W,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* timestep_embedding(t, dim) (models/unet.py:22-39): (n,) int64 -> (n,dim) fp32, [cos | sin] order. */
+int ccn_timestep_embedding(const int64_t* t_dev, float* out_dev, int32_t n, int32_t dim, void* stream);
+
+/* ---- introspection (tests, profiling) -------------------------------------------------------- */
+
+/* After ccn_forward / ccn_sample: copy an intermediate activation out as fp32 NCHW.  Names are the
+ * reference module paths: "in_conv", "down.0" ... "mid2", "up.8" (after the skip add), and
+ * "<block>.film" for the tensor entering norm2.  Synchronises `stream`. */
+int ccn_read_activation(ccn_handle_t h, const char* name, float* out_dev, size_t out_elems, void* stream);
+
+/* Per-kernel-family device time of the next ccn_sample / ccn_forward calls, measured with HIP events
+ * recorded on the launch stream around every kernel (the loop then runs launch by launch instead of
+ * as one graph).  ccn_profile_read synchronises, then fills arrays of capacity `cap`: family name,
+ * summed milliseconds, launch count, and the summed ALGORITHMIC flops (2*MAC) and HBM bytes of those
+ * launches; *n receives the number of families. */
+int ccn_profile_enable(ccn_handle_t h, int32_t on);
+int ccn_profile_read(ccn_handle_t h, const char** names, float* ms, int32_t* calls,
+                     double* flops, double* bytes, int32_t cap, int32_t* n);
+
+/* Algorithmic work of one UNet forward for (B,H,W): conv/linear FLOPs (2*MAC) and minimal HBM bytes
+ * under this handle's storage dtype. */
+int ccn_algorithmic_work(ccn_handle_t h, int32_t B, int32_t H, int32_t W, double* flops, double* bytes);
+
+const char* ccn_last_error(void);
+const char* ccn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCN_HIP_H */

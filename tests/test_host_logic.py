@@ -1,0 +1,135 @@
+"""Host-side logic of the product package (no GPU, no HIP compute calls)."""
+import json
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from clip_feature_codec.diffusion.scheduler import NoiseScheduler
+from clip_feature_codec.io import bitstream
+from clip_feature_codec.eval import metrics
+from clip_feature_codec.models.unet import CLIPCondUNet, infer_arch
+from clip_feature_codec.cli import eval as cli_eval
+from oracle import ref_codec, ref_diffusion
+
+
+def test_scheduler_tables_match_reference_bits(golden):
+    g = golden("scheduler.npz")
+    for sched in ("cosine", "linear"):
+        s = NoiseScheduler(1000, sched, device="cpu")
+        for name in ref_diffusion.TABLE_NAMES:
+            assert np.array_equal(getattr(s, name).numpy(), g[f"{sched}.{name}"]), (sched, name)
+    with pytest.raises(ValueError, match="Unknown schedule"):
+        NoiseScheduler(1000, "quadratic", device="cpu")
+
+
+def test_ddim_tables_match_oracle(golden):
+    g = golden("scheduler.npz")
+    s = NoiseScheduler(1000, "cosine", device="cpu")
+    for steps in (10, 50, 100):
+        assert np.array_equal(s.ddim_timesteps(steps), g[f"ts.{steps}"])
+        for eta in (0.0, 0.5):
+            mine = s.ddim_coefficients(steps, eta)
+            assert np.array_equal(mine, ref_diffusion.ddim_coefficients(ref_diffusion.scheduler_tables(), steps, eta),
+                                  equal_nan=True)
+        # reference quirk Q2 (ddim.py:42): with eta > 0 the direction coefficient sqrt(ab_s - sigma^2) is NaN on the
+        # early cosine-schedule steps (ab_s ~ 2e-6 < sigma^2); reproduced, not fixed
+        assert np.isnan(mine[0, 3]) and not np.isnan(s.ddim_coefficients(steps, 0.0)).any()
+
+
+def test_param_spec_counts(synth):
+    def count(spec):
+        return sum(int(np.prod(s)) for _, s in spec)
+    assert len(synth.unet_param_spec(512, 128, (1, 2, 2))) == 192
+    assert count(synth.unet_param_spec(512, 128, (1, 2, 2))) == 32_530_435
+    assert count(synth.unet_param_spec(512, 32, (1, 2))) == 1_374_147
+    assert count(synth.unet_param_spec(512, 192, (1, 2, 2, 4))) == 815_721_475
+
+
+def test_module_tree_has_reference_keys_and_loads_strict(synth, tiny_sd):
+    net = CLIPCondUNet(z_dim=512, base=32, ch_mult=(1, 2))
+    spec = synth.unet_param_spec(512, 32, (1, 2))
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(s)) for k, s in spec]
+    sd = {k: torch.from_numpy(v) for k, v in tiny_sd.items()}
+    net.load_state_dict(sd, strict=True)
+    assert infer_arch(sd) == dict(z_dim=512, base=32, ch_mult=(1, 2), time_dim=256, img_ch=3)
+    bad = dict(sd); bad.pop("out.bias")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)
+
+
+def test_default_init_consumes_rng_like_torch_modules():
+    """Same module kinds in the same order => same default init as the reference for a given seed."""
+    torch.manual_seed(7); a = CLIPCondUNet(base=32, ch_mult=(1, 2)).state_dict()
+    torch.manual_seed(7); b = CLIPCondUNet(base=32, ch_mult=(1, 2)).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a["out_norm.weight"].min()) == 1.0 and float(a["out_norm.bias"].abs().max()) == 0.0
+
+
+def test_product_refuses_cpu_tensors(tiny_sd):
+    net = CLIPCondUNet(base=32, ch_mult=(1, 2)).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 16, 16), torch.zeros(1, 512), torch.zeros(1, dtype=torch.long))
+    s = NoiseScheduler(device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.q_sample(torch.zeros(1, 3, 8, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 8, 8))
+
+
+def test_bitstream_roundtrip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 256, 512, dtype=np.uint8)
+    p = tmp_path / "a.clp"
+    bitstream.write_bitstream(q.tobytes(), 512, p)
+    blob = p.read_bytes()
+    assert blob[:4] == b"CLPF" and struct.unpack("<I", blob[4:8])[0] == len(blob) - 8
+    assert blob[8:12] == b"\x28\xb5\x2f\xfd"                   # zstd frame magic
+    assert np.array_equal(bitstream.read_bitstream(p), q)
+    assert np.array_equal(ref_codec.read_bitstream(p), q)       # oracle reads the product's file
+    ref_codec.write_bitstream(q.tobytes(), 512, tmp_path / "b.clp")
+    assert np.array_equal(bitstream.read_bitstream(tmp_path / "b.clp"), q)
+    (tmp_path / "bad.clp").write_bytes(b"XXXX" + blob[4:])
+    with pytest.raises(AssertionError, match="Bad magic"):
+        bitstream.read_bitstream(tmp_path / "bad.clp")
+    bitstream.write_bitstream(b"", 0, tmp_path / "e.clp")       # empty payload
+    assert bitstream.read_bitstream(tmp_path / "e.clp").size == 0
+
+
+def test_decode_embedding_matches_oracle():
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, 512, dtype=np.uint8)
+    scale = rng.uniform(1e-4, 1e-3, 512).astype(np.float32); zero = rng.uniform(-0.2, 0, 512).astype(np.float32)
+    z = bitstream.decode_embedding(q, scale, zero)
+    assert z.shape == (1, 512) and z.dtype == np.float32
+    assert np.array_equal(z, ref_codec.decode_z(q, scale, zero))
+    assert abs(float(np.linalg.norm(z)) - 1.0) < 1e-6
+
+
+def test_psnr_known_answers(golden):
+    g = golden("psnr_kat.npz")
+    assert np.array_equal(metrics._to_uint8(g["a"]), g["u8_a"])
+    assert float(metrics.psnr(g["a"], g["b"])) == float(g["psnr_ab"])
+    assert metrics.psnr(g["a"], g["a"]) == float("inf")
+    s = metrics.ssim(g["a"], g["b"])
+    assert 0.0 < s < 1.0 and abs(metrics.ssim(g["a"], g["a"]) - 1.0) < 1e-12
+    assert np.isnan(metrics.lpips_distance(g["a"], g["b"])) and np.isnan(metrics.clip_similarity(g["a"], g["b"]))
+
+
+def test_synth_store_layout(tmp_path, synth):
+    man = synth.write_synth_store(tmp_path / "store", 5, 32, write_clp=bitstream.write_bitstream)
+    meta = np.load(tmp_path / "store" / "codec_meta.npz")
+    assert set(meta.files) == {"scale", "zero", "dim"} and meta["scale"].shape == (512,)
+    assert json.loads((tmp_path / "store" / "manifest.json").read_text()) == man and len(man) == 5
+    z = bitstream.decode_embedding(bitstream.read_bitstream(man[2]["bitstream"]), meta["scale"], meta["zero"])
+    assert np.abs(z[0] - synth.synth_z(5)[2]).max() < 2e-3      # 8-bit quantisation error
+    assert cli_eval.load_original(man[0]["image"], 32).shape == (3, 32, 32)
+
+
+def test_sharding_and_aggregate():
+    assert cli_eval.shard_indices(64, 3, 8) == list(range(3, 64, 8))
+    allidx = sorted(i for r in range(8) for i in cli_eval.shard_indices(61, r, 8))
+    assert allidx == list(range(61))                              # ragged tail covered exactly once
+    assert cli_eval.shard_indices(3, 5, 8) == []                  # more ranks than records
+    rows = np.array([[30.0, 0.9, np.nan, np.nan], [20.0, np.nan, np.nan, np.nan]])
+    agg = cli_eval.aggregate(rows)
+    assert agg["psnr"] == 25.0 and agg["ssim"] == 0.9 and np.isnan(agg["lpips"])
