@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the 256 px / 50-step DDIM reconstruction, batch 8 per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: ccn_sample of 8 images (256x256, base=128,
+ch_mult=(1,2,2)) through 50 DDIM steps, replayed as one hipGraph, inputs resident in HBM.  Ranks hold
+independent batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line with the
+contract fields plus `roofline` (dominant kernel, HIP-event timed in a launch-by-launch pass of the same
+workload) and, at N=1, `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+for p in (str(REPO), str(REPO / "clip-neural-image-conpression_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--base", type=int, default=128)
+    ap.add_argument("--ch-mult", type=str, default="1,2,2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="DDIM steps of the CPU-baseline sample (batch 1)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from clip_feature_codec import _native
+    from clip_feature_codec.utils import synth
+    from clip_feature_codec.models.unet import CLIPCondUNet
+    from clip_feature_codec.diffusion.scheduler import NoiseScheduler
+    from clip_feature_codec.diffusion.ddim import DDIMSampler
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    dev = f"cuda:{local % torch.cuda.device_count()}"
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    _native.load_library()
+
+    ch_mult = tuple(int(v) for v in args.ch_mult.split(","))
+    B, S, T = args.batch, args.size, args.ddim_steps
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, args.base, ch_mult))
+    net = CLIPCondUNet(512, args.base, ch_mult, dtype=args.dtype).to(dev).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    idx = list(range(rank * B, rank * B + B))
+    z = torch.from_numpy(synth.synth_z(world * B)[rank * B:rank * B + B]).to(dev)
+    x_T = torch.from_numpy(synth.start_noise(idx, S, seed_base=100)).to(dev)
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", dev), eta=0.0)
+
+    def step():
+        return sampler.sample(net, z, (B, 3, S, S), steps=T, x_T=x_T)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        x = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x).all()
+    value = world * B * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        nat = net.native()
+        nat.profile(True)
+        sampler.sample(net, z, (B, 3, S, S), steps=T, x_T=x_T)       # launch by launch, HIP events around every kernel
+        fams = nat.profile_read()
+        nat.profile(False)
+        total_ms = sum(f["ms"] for f in fams)
+        dom = max(fams, key=lambda f: f["ms"])
+        tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        flops_fwd, bytes_fwd = nat.algorithmic_work(B, S, S)
+        roofline = {
+            "bound": "mfma", "kernel": dom["name"], "achieved": round(tfs, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+            "frac": round(tfs / PEAK[args.dtype], 4), "traffic": None,
+            "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
+            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["calls"] / 1e9, 3),
+            "kernel_hbm_gbs_algorithmic": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+            "families_ms": {f["name"]: round(f["ms"], 3) for f in fams},
+            "event_pass_ms": round(total_ms, 2),
+            "whole_forward": {"gflop_per_image": round(flops_fwd / B / 1e9, 2), "mb_per_image": round(bytes_fwd / B / 1e6, 1),
+                              "tflops": round(flops_fwd * T * args.steps / dt / 1e12, 2),
+                              "hbm_gbs_algorithmic": round(bytes_fwd * T * args.steps / dt / 1e9, 1),
+                              "hbm_frac": round(bytes_fwd * T * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_unet, ref_diffusion
+        # the box's CPU share, not the host's core count: oversubscribed torch threads crawl under a cgroup quota
+        ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("CCN_CPU_THREADS", "16")))
+        torch.set_num_threads(max(1, ncpu))
+        osd = ref_unet.as_torch_sd(sd)
+        model = ref_unet.make_model(osd)
+        z1, x1 = z[:1].cpu(), x_T[:1].cpu()
+        with torch.no_grad():
+            w0 = time.perf_counter()
+            model(x1, z1, torch.tensor([999]))
+            t_fwd = time.perf_counter() - w0
+        # bounded sample: about 20 s of CPU work, at least 2 and at most --cpu-steps DDIM steps
+        n = max(2, min(args.cpu_steps, T, int(20.0 / max(t_fwd, 1e-3))))
+        tab = ref_diffusion.scheduler_tables()
+        ts = ref_diffusion.ddim_timesteps(1000, T)
+        coefs = ref_diffusion.ddim_coefficients(tab, T)
+        with torch.no_grad():
+            model(x1, z1, torch.tensor([int(ts[0])]))              # warm the CPU caches / thread pool
+            c0 = time.perf_counter()
+            xc = x1
+            for i in range(n):
+                e = model(xc, z1, torch.tensor([int(ts[i])]))
+                xc = ref_diffusion.ddim_update(xc, e, coefs[i])
+            cdt = time.perf_counter() - c0
+        cpu = {"value": round(1.0 / (cdt / n * T), 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"first {n} of {T} DDIM steps (UNet forward + update), batch 1, {S}px, fp32 torch-CPU oracle, "
+                         f"{cdt:.1f}s measured, extrapolated x{T / n:.2f}"}
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec @256px 50-step DDIM, batch=8/GPU", "value": round(value, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{S}px base={args.base} ch_mult={ch_mult} {T}-step DDIM (eta=0), batch={B}/GPU, "
+                                   "key-seeded synthetic weights (out.* x0.1), synthetic z / x_T",
+                       "global_batch": world * B, "parallelism": f"dp{world} (independent batches, no collective in the loop)",
+                       "graph": "hipGraph, one replay per step"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

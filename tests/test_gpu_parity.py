@@ -1,0 +1,276 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle and the reference's
+golden vectors.  fp32 mode is the parity mode (tolerances written at each assert); bf16 mode is the throughput
+mode and is checked against looser, stated bounds (a bf16 forward of the REFERENCE itself differs from fp32
+by 2.7e-3 max-abs on these weights)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from clip_feature_codec import _native
+from clip_feature_codec.models.unet import CLIPCondUNet, timestep_embedding
+from clip_feature_codec.models.blocks import ResBlock, FiLM
+from clip_feature_codec.diffusion.scheduler import NoiseScheduler
+from clip_feature_codec.diffusion.ddim import DDIMSampler
+from oracle import ref_unet, ref_diffusion
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# fp32-mode tolerances.  eps is O(0.1-0.4); activations are O(1-5).
+TOL_EPS_FP32 = 2e-5
+TOL_ACT_FP32 = 1e-4
+TOL_E2E_FP32 = 1e-3       # BASELINE.json north_star: max-abs on the reconstructed tensor
+
+
+def to_dev(a):
+    return (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))).to(DEV)
+
+
+def make_net(sd, base, ch_mult, dtype="fp32", z_dim=512):
+    net = CLIPCondUNet(z_dim=z_dim, base=base, ch_mult=ch_mult, dtype=dtype).to(DEV).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net
+
+
+def maxerr(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+@pytest.fixture(scope="module")
+def tiny_net(tiny_sd):
+    return make_net(tiny_sd, 32, (1, 2))
+
+
+def test_native_library_is_loaded():
+    lib = _native.load_library()
+    assert b"gfx950" in lib.ccn_version()
+    with open("/proc/self/maps") as f:
+        assert "libccn_hip.so" in f.read()
+
+
+def test_timestep_embedding(golden):
+    g = golden("scheduler.npz")
+    for steps in (10, 50):
+        emb = timestep_embedding(to_dev(g[f"ts.{steps}"].astype(np.int64)), 256).cpu().numpy()
+        # device expf/cosf/sinf vs the CPU's: a few ulp of the argument at t*f up to 999 rad
+        assert np.abs(emb - g[f"temb.{steps}"]).max() < 2e-4
+        assert np.abs(emb[:, :8] - g[f"temb.{steps}"][:, :8]).max() < 1.5e-4
+    assert timestep_embedding(to_dev(np.array([5], np.int64)), 7).shape == (1, 7)     # odd dim: zero pad
+    assert float(timestep_embedding(to_dev(np.array([5], np.int64)), 7)[0, 6]) == 0.0
+
+
+def test_film_operator(golden, synth):
+    g = golden("resblock.npz")
+    film = FiLM(32, 256).to(DEV)
+    spec = [(f"down.0.film.{k}", tuple(v.shape)) for k, v in film.state_dict().items()]
+    sd = synth.synth_state_dict(spec, seed=3)
+    film.load_state_dict({k[len("down.0.film."):]: torch.from_numpy(v) for k, v in sd.items()})
+    y = film(to_dev(g["x"]), to_dev(g["h"]))
+    assert y.shape == g["x"].shape                         # the reference's own test (tests/test_blocks.py:10)
+    assert maxerr(y, torch.from_numpy(g["film"])) < 5e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 3e-5), ("bf16", 8e-2)])
+def test_resblock_operator(golden, synth, dtype, tol):
+    g = golden("resblock.npz")
+    rb = ResBlock(32, 256).to(DEV)
+    rb.compute_dtype = dtype
+    spec = [(f"down.0.{k}", tuple(v.shape)) for k, v in rb.state_dict().items()]
+    sd = synth.synth_state_dict(spec, seed=3)
+    rb.load_state_dict({k[len("down.0."):]: torch.from_numpy(v) for k, v in sd.items()})
+    y = rb(to_dev(g["x"]), to_dev(g["h"]))
+    assert maxerr(y, torch.from_numpy(g["y"])) < tol, maxerr(y, torch.from_numpy(g["y"]))
+
+
+def test_unet_taps_fp32(golden, tiny_net):
+    """Every intermediate of the tiny UNet vs the reference's forward-hook captures, in forward order."""
+    g = golden("unet_tiny_taps.npz")
+    eps = tiny_net(to_dev(g["x"]), to_dev(g["z"]), to_dev(g["t"]))
+    report = []
+    for name in ["in_conv", "down.0", "down.1", "down.2", "down.3", "down.5", "mid1", "mid2", "up.0", "up.1"]:
+        ref = g[f"tap.{name}"]
+        got = tiny_net.read_activation(name, ref.shape)
+        report.append((name, maxerr(got, torch.from_numpy(ref)), float(np.abs(ref).max())))
+    # the reference's hooks see the ConvTranspose output BEFORE the skip add; ours is after: compare via the next tap
+    err_eps = maxerr(eps, torch.from_numpy(g["eps"]))
+    msg = "; ".join(f"{n}: err {e:.2e} (|ref| {m:.1f})" for n, e, m in report) + f"; eps err {err_eps:.2e}"
+    for n, e, m in report:
+        assert e < TOL_ACT_FP32, msg
+    assert eps.shape == g["x"].shape and err_eps < TOL_EPS_FP32, msg
+
+
+@pytest.mark.parametrize("base,ch_mult,B,H,W", [
+    (32, (1, 2), 3, 24, 40),        # W not a multiple of the 32-pixel tile, H not of 4 at the deeper levels
+    (48, (2, 1), 2, 16, 16),        # 6 and 12 channels per group, Cout = 96 (N-tile masking)
+    (64, (1, 2, 2), 1, 32, 64),     # three levels, 256 channels at the bottleneck (two N tiles, group spans)
+    (16, (1,), 2, 8, 8),            # 2 channels per group, single level
+])
+def test_forward_shapes_vs_oracle_fp32(synth, base, ch_mult, B, H, W):
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, base, ch_mult), seed=1)
+    net = make_net(sd, base, ch_mult)
+    g = torch.Generator().manual_seed(base + H)
+    x = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B, seed=9))
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        ref = ref_unet.unet_forward(ref_unet.as_torch_sd(sd), x, z, t)
+    eps = net(x.to(DEV), z.to(DEV), t.to(DEV))
+    assert eps.shape == x.shape and eps.dtype == torch.float32 and eps.device == torch.device(DEV)
+    assert maxerr(eps, ref) < TOL_EPS_FP32, maxerr(eps, ref)
+
+
+def test_forward_bf16_vs_oracle(golden, tiny_sd):
+    g = golden("unet_tiny_taps.npz")
+    net = make_net(tiny_sd, 32, (1, 2), dtype="bf16")
+    eps = net(to_dev(g["x"]), to_dev(g["z"]), to_dev(g["t"]))
+    err = maxerr(eps, torch.from_numpy(g["eps"]))
+    assert err < 1e-2, err          # bf16 storage + bf16 MFMA inputs; |eps| ~ 0.2
+
+
+def test_ddim_step_bit_exact(golden):
+    """The update kernel reproduces the reference's fp32 op sequence bit for bit.  The coefficient table is
+    rebuilt from the GOLDEN schedule tables: torch-CPU cos/cumprod round differently on different host CPUs
+    (AVX2 vs AVX-512 paths), so tables recomputed on this box need not equal the build container's to the last bit."""
+    g = golden("c1_sample.npz")
+    gs = golden("scheduler.npz")
+    tables = {k: torch.from_numpy(gs[f"cosine.{k}"]) for k in ref_diffusion.TABLE_NAMES}
+    coefs = ref_diffusion.ddim_coefficients(tables, 10)
+    x = torch.from_numpy(g["x_T"]).clone()
+    for i in range(10):
+        xd = to_dev(x).clone()
+        _native.ddim_step(xd, to_dev(g["eps"][i]), coefs[i, :4])
+        assert np.array_equal(xd.cpu().numpy(), g["x_steps"][i]), f"step {i}"      # byte-identical to the reference
+        x = torch.from_numpy(g["x_steps"][i])
+
+
+def test_q_sample_and_predict_x0_bit_exact():
+    sch = NoiseScheduler(1000, "cosine", DEV)
+    tab = ref_diffusion.scheduler_tables()
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn((3, 3, 16, 16), generator=g); n = torch.randn((3, 3, 16, 16), generator=g); t = torch.tensor([0, 500, 999])
+    xt = sch.q_sample(x0.to(DEV), t.to(DEV), n.to(DEV))
+    assert torch.equal(xt.cpu(), ref_diffusion.q_sample(tab, x0, t, n))
+    back = sch.predict_x0_from_eps(xt, t.to(DEV), n.to(DEV))
+    assert torch.equal(back.cpu(), ref_diffusion.predict_x0_from_eps(tab, xt.cpu(), t, n))
+
+
+def test_c1_teacher_forced_and_end_to_end_fp32(golden, tiny_net):
+    """BASELINE config 1 shapes: 64 px, base 32, (1,2), 10 steps.  Per-step (teacher-forced) and end-to-end."""
+    g = golden("c1_sample.npz")
+    z = to_dev(g["z"])
+    ts = ref_diffusion.ddim_timesteps(1000, 10)
+    x_in = [g["x_T"]] + [g["x_steps"][i] for i in range(9)]
+    worst = 0.0
+    for i in range(10):
+        eps = tiny_net(to_dev(x_in[i]), z, to_dev(np.array([ts[i]], np.int64)))
+        worst = max(worst, maxerr(eps, torch.from_numpy(g["eps"][i])))
+    assert worst < TOL_EPS_FP32, worst
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), eta=0.0)
+    x = sampler.sample(tiny_net, z, (1, 3, 64, 64), steps=10, x_T=to_dev(g["x_T"]))
+    assert maxerr(x, torch.from_numpy(g["x_final"])) < TOL_E2E_FP32, maxerr(x, torch.from_numpy(g["x_final"]))
+
+
+def test_graph_equals_stepwise_and_is_deterministic(golden, tiny_net):
+    g = golden("c1_sample.npz")
+    z, xT = to_dev(g["z"]), to_dev(g["x_T"])
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), eta=0.0)
+    a = sampler.sample(tiny_net, z, (1, 3, 64, 64), steps=10, x_T=xT)
+    b = sampler.sample(tiny_net, z, (1, 3, 64, 64), steps=10, x_T=xT)          # graph replay
+    sampler.use_graph = False
+    c = sampler.sample(tiny_net, z, (1, 3, 64, 64), steps=10, x_T=xT)          # launch by launch
+    d = sampler.sample(lambda x, zz, t: tiny_net(x, zz, t), z, (1, 3, 64, 64), steps=10, x_T=xT)   # generic callable route
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert maxerr(a, d) < 1e-5      # conditioning via the int64 forward path instead of the hoisted table
+
+
+def test_batch_rows_are_independent(synth, tiny_net):
+    """Independent units: a batch of 3 equals three batches of 1, bit for bit (what makes rank sharding exact)."""
+    z = to_dev(synth.synth_z(3, seed=50)); xT = to_dev(synth.start_noise([7, 8, 9], 32, seed_base=1))
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), eta=0.0)
+    full = sampler.sample(tiny_net, z, (3, 3, 32, 32), steps=4, x_T=xT)
+    for i in range(3):
+        one = sampler.sample(tiny_net, z[i:i + 1], (1, 3, 32, 32), steps=4, x_T=xT[i:i + 1])
+        assert torch.equal(one[0], full[i]), i
+
+
+def test_eta_positive_runs_stepwise(tiny_net, synth):
+    z = to_dev(synth.synth_z(1)); xT = to_dev(synth.start_noise([0], 32))
+    x = DDIMSampler(NoiseScheduler(1000, "linear", DEV), eta=0.3).sample(tiny_net, z, (1, 3, 32, 32), steps=5, x_T=xT)
+    assert x.shape == (1, 3, 32, 32)
+
+
+def test_error_paths(tiny_net):
+    with pytest.raises(ValueError):
+        tiny_net(torch.zeros(1, 3, 30, 30, device=DEV), torch.zeros(1, 512, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+    with pytest.raises(ValueError):
+        tiny_net(torch.zeros(2, 3, 32, 32, device=DEV), torch.zeros(1, 512, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV))
+    nat = _native.NativeUNet(512, 32, (1, 2), 256, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        nat.load_state_dict({"out.bias": torch.zeros(3)})
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        nat.load_state_dict({"nope": torch.zeros(3)})
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        nat.load_state_dict({"out.bias": torch.zeros(4)})
+
+
+# ---------------------------------------------------------------- BASELINE config 2 sizes (256 px, base 128, (1,2,2))
+@pytest.fixture(scope="module")
+def c2_sd(synth):
+    return synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
+
+
+def _check_packed(name, got, g, tol):
+    got = got[0].detach().cpu()
+    sub = got[:, ::4, ::4].numpy()
+    err = float(np.abs(sub - g[f"{name}.sub"]).max())
+    mean_err = float(np.abs(got.double().mean((1, 2)).numpy() - g[f"{name}.mean"]).max())
+    abssum = float(got.double().abs().sum())
+    assert err < tol, (name, err)
+    assert mean_err < tol and abs(abssum / float(g[f"{name}.abssum"]) - 1) < 1e-3, (name, mean_err, abssum)
+    return err
+
+
+def test_c2_forward_fp32_vs_reference(golden, synth, c2_sd):
+    g = golden("c2_sample.npz")
+    net = make_net(c2_sd, 128, (1, 2, 2))
+    xT = to_dev(synth.start_noise([0], 256, seed_base=100)); z = to_dev(synth.synth_z(1))
+    e0 = net(xT, z, to_dev(np.array([999], np.int64)))
+    e1 = net(xT * 0.5, z, to_dev(np.array([500], np.int64)))
+    _check_packed("eps_t999", e0, g, TOL_EPS_FP32)
+    _check_packed("eps_t500_halfx", e1, g, TOL_EPS_FP32)
+
+
+def test_c2_50_step_fp32_vs_reference(golden, synth, c2_sd):
+    """The headline parity gate: 256 px, 50 DDIM steps, same seed / z as the reference's device='cpu' run."""
+    g = golden("c2_sample.npz")
+    net = make_net(c2_sd, 128, (1, 2, 2))
+    xT = to_dev(synth.start_noise([0], 256, seed_base=100)); z = to_dev(synth.synth_z(1))
+    x = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0).sample(net, z, (1, 3, 256, 256), steps=50, x_T=xT)
+    err = _check_packed("x_final", x, g, TOL_E2E_FP32)
+    print(f"C2 50-step fp32 max-abs vs reference: {err:.3e}")
+
+
+def test_c2_bf16_reported_deviation(golden, synth, c2_sd):
+    """bf16 throughput mode at full size: bounded, and reported.  The reference under bf16 autocast deviates from
+    its own fp32 run by 2.7e-3 per forward and 0.30 max-abs / 0.037 mean-abs over 50 steps on these weights."""
+    g = golden("c2_sample.npz")
+    net = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")
+    xT = to_dev(synth.start_noise([0], 256, seed_base=100)); z = to_dev(synth.synth_z(1))
+    e0 = net(xT, z, to_dev(np.array([999], np.int64)))
+    err = float(np.abs(e0[0, :, ::4, ::4].cpu().numpy() - g["eps_t999.sub"]).max())
+    assert err < 2e-2, err
+    x = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0).sample(net, z, (1, 3, 256, 256), steps=50, x_T=xT)
+    d = np.abs(x[0, :, ::4, ::4].cpu().numpy() - g["x_final.sub"])
+    print(f"C2 bf16: forward max-abs {err:.3e}; 50-step max-abs {d.max():.3e} mean-abs {d.mean():.3e}")
+    assert d.mean() < 0.15 and np.isfinite(d).all()
+
+
+def test_c2_batch8_rows_equal_batch1_bf16(synth, c2_sd):
+    """Full BASELINE size property: batch 8 (the bench workload) equals per-record runs bit for bit."""
+    net = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")
+    z = to_dev(synth.synth_z(8)); xT = to_dev(synth.start_noise(range(8), 256, seed_base=100))
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0)
+    full = sampler.sample(net, z, (8, 3, 256, 256), steps=3, x_T=xT)
+    one = sampler.sample(net, z[5:6], (1, 3, 256, 256), steps=3, x_T=xT[5:6])
+    assert torch.equal(one[0], full[5]) and torch.isfinite(full).all()
