@@ -286,9 +286,9 @@ int pack_stem(ccn_handle_s* h, ConvW& cw, const std::string& name)      // Conv2
 }
 
 // ---- plan -------------------------------------------------------------------------------------------------
-struct ConvGeom { int Hout, Wout, MH, MW, OS, npar, ntaps, n_ty, n_tx, n_nt; };
+struct ConvGeom { int Hout, Wout, MH, MW, OS, npar, ntaps, n_ty, n_tx, n_nt, th; };
 
-ConvGeom conv_geom(const ConvW& cw, int Hin, int Win)
+ConvGeom conv_geom(const ConvW& cw, int B, int Hin, int Win)
 {
     ConvGeom g{};
     switch (cw.kind) {
@@ -297,7 +297,9 @@ ConvGeom conv_geom(const ConvW& cw, int Hin, int Win)
         case KIND_STEM: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 1; break;
         default: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 9; break;
     }
-    g.n_ty = ceil_div(g.MH, 4); g.n_tx = ceil_div(g.MW, 32); g.n_nt = cw.Cout_pad / cw.BN;
+    g.n_nt = cw.Cout_pad / cw.BN;
+    g.th = conv_tile_rows(cw.kind, cw.BN, B, g.MH, g.MW, g.npar, g.n_nt);
+    g.n_ty = ceil_div(g.MH, g.th); g.n_tx = ceil_div(g.MW, 32);
     return g;
 }
 
@@ -340,14 +342,14 @@ struct PlanBuilder {
     void conv(const ConvW& cw, int family, const TensorRef& in, TensorRef& out, const float2* gn_ab, int film_off,
               const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
     {
-        const ConvGeom g = conv_geom(cw, in.H, in.W);
+        const ConvGeom g = conv_geom(cw, B, in.H, in.W);
         ConvArgs a{};
         a.in = in.p; a.w = cw.w; a.bias = cw.bias; a.out = out.p;
         a.gn_ab = gn_ab; a.film = nullptr; a.res = res ? res->p : nullptr;
         a.B = B; a.Hin = in.H; a.Win = in.W; a.Cin = cw.Cin; a.Cin_pad = cw.Cin_pad;
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = cw.Cout; a.Cout_pad = cw.Cout_pad;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
-        a.n_ty = g.n_ty; a.n_tx = g.n_tx; a.n_nt = g.n_nt;
+        a.n_ty = g.n_ty; a.n_tx = g.n_tx; a.n_nt = g.n_nt; a.th = g.th;
         const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
         a.nchunk = cw.Cin_pad / cke;
         a.silu = 1;

@@ -1,0 +1,113 @@
+// Device-side helpers shared by the convolution kernels (types, 16-byte pack/unpack, MFMA wrappers,
+// the GroupNorm+SiLU prologue transform).
+#pragma once
+#include "ccn_internal.h"
+
+namespace ccn {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { A_NHWC = 0, A_IM2COL = 1 };
+enum { EPI_NHWC = 0, EPI_HEAD = 1 };
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32, RNE
+}
+
+template <typename T> __device__ __forceinline__ float silu_f(float v);
+template <> __device__ __forceinline__ float silu_f<float>(float v) { return v / (1.0f + expf(-v)); }
+template <> __device__ __forceinline__ float silu_f<__bf16>(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+// 16 bytes of T -> EPC floats and back
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ void unpack(const u32x4& r, float* v) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* v) {
+        return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    }
+};
+template <> struct Vec16<__bf16> {
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ void unpack(const u32x4& r, float* v) {
+        v[0] = bf_lo(r.x); v[1] = bf_hi(r.x); v[2] = bf_lo(r.y); v[3] = bf_hi(r.y);
+        v[4] = bf_lo(r.z); v[5] = bf_hi(r.z); v[6] = bf_lo(r.w); v[7] = bf_hi(r.w);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* v) {
+        return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+};
+
+template <typename T> __device__ __forceinline__ void mfma16(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mfma16<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 a4 = __builtin_bit_cast(f32x4, a), b4 = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mfma16<__bf16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+
+// ---- GroupNorm-apply (+ SiLU) on one 16-byte chunk while staging the A operand ----------------------------
+// fp32 (parity mode): y = fma(x, a, c); silu(y) = y / (1 + expf(-y)) with full-precision expf and a true division.
+// bf16 (throughput mode): packed fp32 math, exp2 with log2(e) folded into a second scale/shift pair, v_rcp.
+template <typename T> struct GnCoef;
+template <> struct GnCoef<float> {
+    float a[4], c[4];
+    __device__ __forceinline__ void load(const float2* ab, bool valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float2 v = valid ? ab[e] : make_float2(1.f, 0.f); a[e] = v.x; c[e] = v.y; }
+    }
+    template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
+        float v[4];
+        Vec16<float>::unpack(raw, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = fmaf(v[e], a[e], c[e]);
+            if (SILU) y = y / (1.0f + expf(-y));
+            v[e] = y;
+        }
+        return Vec16<float>::pack(v);
+    }
+};
+template <> struct GnCoef<__bf16> {
+    f32x2 a[4], c[4], an[4], cn[4];
+    __device__ __forceinline__ void load(const float2* ab, bool valid) {
+        const float nl2e = -1.4426950408889634f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 v0 = valid ? ab[2 * e] : make_float2(1.f, 0.f), v1 = valid ? ab[2 * e + 1] : make_float2(1.f, 0.f);
+            a[e] = f32x2{v0.x, v1.x}; c[e] = f32x2{v0.y, v1.y};
+            an[e] = a[e] * nl2e; cn[e] = c[e] * nl2e;
+        }
+    }
+    template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned u = raw[e];
+            const f32x2 x = {bf_lo(u), bf_hi(u)};
+            f32x2 y = __builtin_elementwise_fma(x, a[e], c[e]);
+            if (SILU) {
+                const f32x2 t = __builtin_elementwise_fma(x, an[e], cn[e]);          // -y * log2(e)
+                const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+                y = y * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            }
+            o[e] = pack_bf2(y[0], y[1]);
+        }
+        return o;
+    }
+};
+
+}  // namespace ccn

@@ -31,6 +31,8 @@ struct ConvArgs {
     int film_bstride;
     int B, Hin, Win, Cin, Cin_pad, Hout, Wout, Cout, Cout_pad;
     int MH, MW, OS, npar;
+    int dbg;                // ablation switches for profiling (CCN_DBG env): 1 no A staging in loop, 2 no B staging, 4 no MFMA, 8 no epilogue
+    int th;                 // tile rows of 32 pixels per workgroup (4; 8 for the large warp-specialised tiles)
     int n_ty, n_tx, n_nt, nchunk, ntaps;
     int silu;               // SiLU after the prologue GroupNorm
     int cpg, G, nslot;      // output GroupNorm geometry
@@ -46,6 +48,13 @@ int conv_bn_for(int cout, int kind);                       // N-tile width used 
 size_t conv_lds_bytes(int dtype, int kind, int bn);
 hipError_t conv_prepare();                                 // raise dynamic-LDS limits once
 hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream_t s);
+// rows of 32 pixels per workgroup tile for this layer (decided once, at plan time)
+int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt);
+// warp-specialised kernel (ccn_conv_ws.hip): 3x3 s1 and ConvTranspose parities, BN 64/128
+bool conv_ws_enabled();
+bool conv_ws_supported(int kind, int bn);
+hipError_t conv_ws_prepare();
+hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s);
 
 // ---- GroupNorm finalize: partial sums -> per-(b,channel) scale/shift --------------------------------
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C,

@@ -17,62 +17,10 @@
 // half h reads chunk 2*kk+h of its A row (a pixel) and of its B row (an output channel), so the K order seen by
 // the two operands is identical by construction.  LDS rows are XOR-swizzled by ((row>>1)&7) at 16-B granularity:
 // 32 consecutive rows read at one chunk index hit 16 distinct 16-B slots per ds_read_b128 lane group.
-#include "ccn_internal.h"
+#include "ccn_device.h"
+#include <cstdlib>
 
 namespace ccn {
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-enum { A_NHWC = 0, A_IM2COL = 1 };
-enum { EPI_NHWC = 0, EPI_HEAD = 1 };
-
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32, RNE
-}
-
-template <typename T> __device__ __forceinline__ float silu_f(float v);
-template <> __device__ __forceinline__ float silu_f<float>(float v) { return v / (1.0f + expf(-v)); }
-template <> __device__ __forceinline__ float silu_f<__bf16>(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
-
-// 16 bytes of T -> EPC floats and back
-template <typename T> struct Vec16;
-template <> struct Vec16<float> {
-    static constexpr int EPC = 4;
-    static __device__ __forceinline__ void unpack(const u32x4& r, float* v) {
-        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
-    }
-    static __device__ __forceinline__ u32x4 pack(const float* v) {
-        return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    }
-};
-template <> struct Vec16<__bf16> {
-    static constexpr int EPC = 8;
-    static __device__ __forceinline__ void unpack(const u32x4& r, float* v) {
-        v[0] = bf_lo(r.x); v[1] = bf_hi(r.x); v[2] = bf_lo(r.y); v[3] = bf_hi(r.y);
-        v[4] = bf_lo(r.z); v[5] = bf_hi(r.z); v[6] = bf_lo(r.w); v[7] = bf_hi(r.w);
-    }
-    static __device__ __forceinline__ u32x4 pack(const float* v) {
-        return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-    }
-};
-
-template <typename T> __device__ __forceinline__ void mfma16(f32x16& acc, const u32x4& a, const u32x4& b);
-template <> __device__ __forceinline__ void mfma16<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
-    const f32x4 a4 = __builtin_bit_cast(f32x4, a), b4 = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc, 0, 0, 0);
-}
-template <> __device__ __forceinline__ void mfma16<__bf16>(f32x16& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-}
 
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -153,14 +101,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             const int cbase = chunk * CKE + ck * EPC;
             const bool cvalid = cbase < a.Cin;
             const bool gn = a.gn_ab != nullptr;
-            float ga[EPC], gc[EPC];
-            if (gn && cvalid) {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { const float2 v = a.gn_ab[(size_t)b * a.Cin + cbase + e]; ga[e] = v.x; gc[e] = v.y; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { ga[e] = 1.0f; gc[e] = 0.0f; }
-            }
+            GnCoef<T> gk;
+            gk.load(a.gn_ab + (size_t)b * a.Cin + (cvalid ? cbase : 0), gn && cvalid);
             const int iy0 = IS * my0 - 1, ix0 = IS * mx0 - 1;
 #pragma unroll
             for (int g0 = 0; g0 < AIT; g0 += GRP) {
@@ -187,17 +129,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                         const int px = (tid >> 3) + 32 * i;
                         if (px < HG::ROWS * HPITCH) {
                             u32x4 o = raw[u];
-                            if (((okm >> u) & 1u) && gn) {                       // zero padding applies AFTER GroupNorm+SiLU
-                                float v[EPC];
-                                Vec16<T>::unpack(raw[u], v);
-#pragma unroll
-                                for (int e = 0; e < EPC; ++e) {
-                                    float y = fmaf(v[e], ga[e], gc[e]);
-                                    if constexpr (EPI == EPI_NHWC) y = silu_f<T>(y);   // head: out_norm has no activation (unet.py:105)
-                                    v[e] = y;
-                                }
-                                o = Vec16<T>::pack(v);
-                            }
+                            if (((okm >> u) & 1u) && gn)       // zero padding applies AFTER GroupNorm+SiLU; head: no SiLU (unet.py:105)
+                                o = gk.template apply<EPI == EPI_NHWC>(raw[u]);
                             *(u32x4*)(As + px * 128 + (((ck ^ (px >> 1)) & 7) << 4)) = o;
                         }
                     }
@@ -470,8 +403,29 @@ hipError_t conv_prepare()
     return hipSuccess;
 }
 
+bool conv_ws_enabled()
+{
+    static const int on = getenv("CCN_CONV_V1") ? 0 : 1;      // CCN_CONV_V1=1: A/B switch back to the 4-wave kernel
+    return on != 0;
+}
+
+int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt)
+{
+    if (!conv_ws_enabled() || !conv_ws_supported(kind, bn)) return 4;
+    // 8-row tiles halve the weight traffic and the halo overhead; keep >= 2 workgroups per CU
+    const long blocks8 = (long)B * ((MH + 7) / 8) * ((MW + 31) / 32) * npar * n_nt;
+    return blocks8 >= 512 ? 8 : 4;
+}
+
 hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream_t s)
 {
+    if (conv_ws_enabled() && conv_ws_supported(kind, bn)) {
+        static const int dbg = getenv("CCN_DBG") ? atoi(getenv("CCN_DBG")) : 0;
+        if (!dbg) return launch_conv_ws(dtype, bn, a, s);
+        ConvArgs d = a; d.dbg = dbg;
+        return launch_conv_ws(dtype, bn, d, s);
+    }
+    if (a.th != 4) return hipErrorInvalidValue;
     const conv_fn_t fn = pick(dtype, kind, bn);
     const unsigned grid = (unsigned)(a.B * a.n_ty * a.n_tx * a.npar * a.n_nt);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), conv_lds_bytes(dtype, kind, bn), s, a);

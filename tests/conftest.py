@@ -48,3 +48,15 @@ def synth():
 def tiny_sd(synth):
     """Key-seeded weights of the C1 architecture (base 32, ch_mult (1,2))."""
     return synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+
+
+def bits_or_close(a, b, rtol=1e-4, atol=1e-6, what=""):
+    """Bit equality where this host reproduces the build container's torch-CPU rounding (it does there: the
+    fixtures were generated on it); on another CPU model torch's vectorised cos/exp/conv kernels may round
+    differently in the last bits, so fall back to a tight tolerance and say so."""
+    import warnings
+    a, b = np.asarray(a), np.asarray(b)
+    if np.array_equal(a, b, equal_nan=True):
+        return
+    assert a.shape == b.shape and np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True), f"{what}: max abs diff {np.abs(a - b).max()}"
+    warnings.warn(f"{what}: equal to the golden vector only within rtol={rtol} on this host CPU (not bit-identical)")

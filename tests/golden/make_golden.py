@@ -83,6 +83,10 @@ def main() -> None:
         ts = torch.linspace(999, 0, steps).long()
         out[f"ts.{steps}"] = ts.numpy()
         out[f"temb.{steps}"] = timestep_embedding(ts, 256).numpy()
+        # per-step DDIM coefficients as THIS host's torch computes them from the reference tables (0-d tensor sqrt
+        # results were seen to differ by 1 ulp on another CPU model, so the bit-exact update tests read them from here)
+        out[f"coef.{steps}"] = ref_diffusion.ddim_coefficients({k: getattr(NoiseScheduler(1000, "cosine", "cpu"), k)
+                                                                for k in ref_diffusion.TABLE_NAMES}, steps)
         assert torch.equal(ref_unet.timestep_embedding(ts, 256), timestep_embedding(ts, 256))
     np.savez_compressed(HERE / "scheduler.npz", **out)
     print("scheduler.npz", sum(v.nbytes for v in out.values()))

