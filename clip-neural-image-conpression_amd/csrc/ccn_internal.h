@@ -31,6 +31,7 @@ struct ConvArgs {
     int film_bstride;
     int B, Hin, Win, Cin, Cin_pad, Hout, Wout, Cout, Cout_pad;
     int MH, MW, OS, npar;
+    unsigned long long* stamps;   // in-kernel s_memtime stamps [block][8] (diagnostic builds of the launch only), or null
     int dbg;                // ablation switches for profiling (CCN_DBG env): 1 no A staging in loop, 2 no B staging, 4 no MFMA, 8 no epilogue
     int th;                 // tile rows of 32 pixels per workgroup (4; 8 for the large warp-specialised tiles)
     int n_ty, n_tx, n_nt, nchunk, ntaps;

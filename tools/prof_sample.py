@@ -25,3 +25,8 @@ for _ in range(a.reps):
     x = s.sample(net, z, (a.batch, 3, a.size, a.size), steps=a.steps, x_T=xT)
 torch.cuda.synchronize()
 print("ok", float(x.abs().mean()))
+import os, ctypes
+if os.environ.get("CCN_STAMPS"):
+    from clip_feature_codec import _native
+    lib = _native.load_library()
+    print("stamps dump rc", lib.ccn_internal_dump_stamps(b"gpurun_out/stamps.txt"))
