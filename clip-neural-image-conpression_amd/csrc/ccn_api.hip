@@ -89,7 +89,7 @@ struct Launch {
 };
 
 const char* kFamilies[] = {"conv3x3_s1_igemm", "conv3x3_s2_igemm", "convT4x4_s2_igemm", "stem_conv_igemm",
-                           "head_conv_ddim", "gn_finalize", "conditioning", "layout"};
+                           "head_conv_ddim", "gn_finalize", "conditioning", "gn_silu_prepass"};
 enum { F_C3S1 = 0, F_C3S2, F_CT4, F_STEM, F_HEAD, F_GNF, F_COND, F_LAYOUT, F_COUNT };
 
 struct Bump {
@@ -401,16 +401,31 @@ struct PlanBuilder {
         return ab;
     }
 
+    // GroupNorm-apply + SiLU as a separate pass when the consuming conv would redo it per N tile (C >= 256)
+    TensorRef preact(const TensorRef& t, const float2* ab)
+    {
+        TensorRef o = new_tensor(t.C, t.H, t.W);
+        const int dtype = h->cfg.dtype, Bc = B, HW = t.H * t.W, C = t.C;
+        const void* src = t.p; void* dst = o.p;
+        Launch L{F_LAYOUT, 0.0, 2.0 * B * HW * (double)C * h->elem, nullptr};
+        L.fn = [=](hipStream_t s, const StepCtx&) -> hipError_t { return launch_gn_act(dtype, src, ab, dst, Bc, HW, C, s); };
+        plan->ops.push_back(std::move(L));
+        return o;
+    }
+
     // x + conv2(SiLU(GN2(FiLM(conv1(SiLU(GN1(x))))))) -- models/blocks.py:40-44
     TensorRef resblock(const ResW& r, const TensorRef& x, bool out_feeds_gn, int film_off = -2)
     {
+        const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256;
         const float2* ab1 = gn(x, r.n1);
         TensorRef y = new_tensor(r.C, x.H, x.W);
-        conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
+        if (pre) { TensorRef xa = preact(x, ab1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
+        else conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
         plan->named[r.prefix + ".film"] = y;
         const float2* ab2 = gn(y, r.n2);
         TensorRef o = new_tensor(r.C, x.H, x.W);
-        conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
+        if (pre) { TensorRef ya = preact(y, ab2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
+        else conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
         plan->named[r.prefix] = o;
         return o;
     }

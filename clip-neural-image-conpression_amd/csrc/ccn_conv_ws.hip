@@ -36,7 +36,8 @@ template <int TH, int BN, int TPS> struct WsLds {
     static constexpr int B_BYTES = TPS * BT_BYTES;           // one stage
     static constexpr int LOOP = 2 * A_BYTES + 2 * B_BYTES;
     static constexpr int CP = BN + 4;
-    static constexpr int CS_BYTES = 128 * CP * 4;
+    static constexpr int CS1_BYTES = 128 * CP * 4;           // fp32 epilogue tile of one 128-pixel pass
+    static constexpr int CS_BYTES = (TH / 4) * CS1_BYTES;    // all passes at once: one barrier for the whole epilogue
     static constexpr int RED_BYTES = 8 * BN * 2 * 4 + BN * 2 * 4;
     static constexpr int TOTAL = LOOP > CS_BYTES + RED_BYTES ? LOOP : CS_BYTES + RED_BYTES;
 };
@@ -52,6 +53,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     constexpr int EPC = Vec16<T>::EPC;
     constexpr int CKE = 8 * EPC;
     constexpr int NSPC = NTAPS / TPS;           // stages (barriers) per Cin chunk
+    // producer waves 4..7: NB weight waves then NA input waves.  8-row tiles move 16 KB of weights per stage (one wave
+    // keeps up) and carry the GroupNorm+SiLU VALU work on 1.7x more input, so they get 3 input waves; 4-row tiles 2 + 2.
+    constexpr int NB = MF == 4 ? 1 : 2, NA = 4 - NB;
+    constexpr int A0 = 4 + NB;                  // first A-producer wave
     static_assert(NSPC * TPS == NTAPS && NSPC >= 2, "taps must split evenly into >= 2 stages per chunk");
     using G = WsGeom<TH>;
     using L = WsLds<TH, BN, TPS>;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     const int iy0 = my0 - 1, ix0 = mx0 - 1;
     // diagnostic stamps (a.stamps is null outside profiling runs): slot 0 entry, 1 prologue done, 2 loop done, 3 exit, per role
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == 6))
+        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0))
             a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 4 + slot] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
@@ -165,45 +170,49 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
             }
         }
     };
-    // one pass = 128 pixels (4 tile rows): residual rows requested before the barrier that publishes Cs
-    auto epi_pass = [&](int pass) __attribute__((always_inline)) {
-        u32x4 rres[NIT][EPC == 8 ? 1 : 2];
-        size_t eoff[NIT];
+    // Whole tile at once: every residual / skip row is requested before the single barrier that publishes the fp32
+    // tiles (one 128-pixel tile per 4 tile rows), so the HBM latency of the residual overlaps the accumulator hand-off.
+    auto epi_all = [&]() __attribute__((always_inline)) {
+        u32x4 rres[NPASS * NIT][EPC == 8 ? 1 : 2];
+        size_t eoff[NPASS * NIT];
         unsigned vmask = 0;
 #pragma unroll
-        for (int itp = 0; itp < NIT; ++itp) {
+        for (int q = 0; q < NPASS * NIT; ++q) {
+            const int pass = q / NIT, itp = q - pass * NIT;
             const int m = itp * PSL + ps;
             const int my = my0 + pass * 4 + (m >> 5), mx = mx0 + (m & 31);
             const bool v = nvalid && my < a.MH && mx < a.MW;
             const int oy = my * a.OS + py, ox = mx * a.OS + px_;
-            eoff[itp] = (((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + nb) * sizeof(T);
-            if (v) vmask |= 1u << itp;
+            eoff[q] = (((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + nb) * sizeof(T);
+            if (v) vmask |= 1u << q;
 #pragma unroll
             for (int w = 0; w < (EPC == 8 ? 1 : 2); ++w) {
-                rres[itp][w] = u32x4{0u, 0u, 0u, 0u};
-                if (v && resb) rres[itp][w] = *(const u32x4*)(resb + eoff[itp] + 16 * w);
+                rres[q][w] = u32x4{0u, 0u, 0u, 0u};
+                if (v && resb) rres[q][w] = *(const u32x4*)(resb + eoff[q] + 16 * w);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int itp = 0; itp < NIT; ++itp) {
-            if ((vmask >> itp) & 1u) {
+        for (int q = 0; q < NPASS * NIT; ++q) {
+            if ((vmask >> q) & 1u) {
+                const int pass = q / NIT, itp = q - pass * NIT;
                 const int m = itp * PSL + ps;
+                const float* cs = Cs + pass * (L::CS1_BYTES / 4) + m * CP + o * 8;
                 float v[8];
-                const f32x4 c0 = *(const f32x4*)(Cs + m * CP + o * 8), c1 = *(const f32x4*)(Cs + m * CP + o * 8 + 4);
+                const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], f1[e], f2[e]);
                 if (resb) {
                     float rv[8];
-                    Vec16<T>::unpack(rres[itp][0], rv);
-                    if constexpr (EPC == 4) Vec16<T>::unpack(rres[itp][1], rv + 4);
+                    Vec16<T>::unpack(rres[q][0], rv);
+                    if constexpr (EPC == 4) Vec16<T>::unpack(rres[q][1], rv + 4);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
-                *(u32x4*)(outb + eoff[itp]) = Vec16<T>::pack(v);
-                if constexpr (EPC == 4) *(u32x4*)(outb + eoff[itp] + 16) = Vec16<T>::pack(v + 4);
+                *(u32x4*)(outb + eoff[q]) = Vec16<T>::pack(v);
+                if constexpr (EPC == 4) *(u32x4*)(outb + eoff[q] + 16) = Vec16<T>::pack(v + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
             }
@@ -211,108 +220,115 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     };
     const bool do_epi = !(a.dbg & 8);
 
-    if (wave >= 6) {
-        // ------------------------------------------------------------------ A producers (2 waves): input halo of the NEXT chunk
-        // All of its 16-byte units are requested at stage 0 of the current chunk (HBM latency has a whole stage to
-        // drain) and retired -- GroupNorm-apply + SiLU, ds_write into the other A buffer -- over stages 1..NSPC-1.
-        const int ptid = tid - 384, ck = ptid & 7;
-        constexpr int AIT = (G::AU + 127) / 128;                  // units per A-producer thread per chunk
-        constexpr int UPS = (AIT + NSPC - 2) / (NSPC - 1);        // units retired per stage
+    if (wave >= A0) {
+        // ------------------------------------------------------------------ A producers (2 waves): input halo, ONE CHUNK AHEAD IN REGISTERS
+        // Software pipeline in registers: while the consumers work on chunk c, these waves hold chunk c+1's 16-byte units
+        // (requested a whole chunk earlier), retire a slice of them per stage -- GroupNorm-apply + SiLU, ds_write into the
+        // other A buffer -- and immediately re-request the same slots for chunk c+2.  No wait on memory in steady state.
+        const int ptid = tid - A0 * 64, ck = ptid & 7;
+        constexpr int AIT = (G::AU + NA * 64 - 1) / (NA * 64);                  // units per A-producer thread per chunk
+        constexpr int UPS = (AIT + NSPC - 1) / NSPC;              // units retired (and re-requested) per stage
         u32x4 areg[AIT];
-        unsigned aok = 0;
-        GnCoef<T> gk;
+        GnCoef<T> gk, gk_next;                   // coefficients of the chunk being retired / of the one after it
+        // unit i of this thread: halo pixel (ptid>>3) + 16*i, channel slice ck
+        auto a_off = [&](int i) __attribute__((always_inline)) -> unsigned {
+            const int px = (ptid >> 3) + NA * 8 * i;
+            const int hy = px / HPITCH, hx = px - hy * HPITCH;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = px < G::HROWS * HPITCH && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            return ok ? (unsigned)(((b * a.Hin + iy) * a.Win + ix) * a.Cin + ck * EPC) * (unsigned)sizeof(T) : OOB;
+        };
+        auto a_req = [&](int chunk, int i) __attribute__((always_inline)) {          // zeros if the chunk / slice / pixel does not exist
+            const bool cv = chunk < a.nchunk && chunk * CKE + ck * EPC < a.Cin;
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_srd(cv ? chunk : 0), cv ? a_off(i) : OOB, 0, 0);
+        };
+        // vmcnt retires in order: coefficient loads are always issued BEFORE the input requests of the same stage, so
+        // waiting for them never waits for HBM
+        auto gk_req = [&](GnCoef<T>& dst, int chunk) __attribute__((always_inline)) {
+            const int cb = chunk * CKE + ck * EPC;
+            const bool cv = chunk < a.nchunk && cb < a.Cin;
+            dst.load(a.gn_ab + (size_t)b * a.Cin + (cv ? cb : 0), gn && cv);
+        };
+        gk_req(gk, 1);
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) a_req(1, i);
         __syncthreads();                                           // prologue tiles visible
         stamp(1);
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-            const bool more = chunk + 1 < a.nchunk;
+            const bool more = chunk + 1 < a.nchunk && !(a.dbg & 1);
             unsigned char* const Ad = As + ((chunk + 1) & 1) * L::A_BYTES;
 #pragma unroll
             for (int g = 0; g < NSPC; ++g) {
-                if (more && !(a.dbg & 1)) {
-                    if (g == 0) {
-                        const int cb = (chunk + 1) * CKE + ck * EPC;
-                        const bool cv = cb < a.Cin;
-                        gk.load(a.gn_ab + (size_t)b * a.Cin + (cv ? cb : 0), gn && cv);
-                        const auto srd = in_srd(chunk + 1);
-                        aok = 0;
+                if (more) {
+                    if (g == NSPC - 1) gk_req(gk_next, chunk + 2);
 #pragma unroll
-                        for (int i = 0; i < AIT; ++i) {           // offsets are recomputed per chunk: cheaper than 22 live registers
-                            const int px = (ptid >> 3) + 16 * i;
-                            const int hy = px / HPITCH, hx = px - hy * HPITCH;
-                            const int iy = iy0 + hy, ix = ix0 + hx;
-                            const bool ok = cv && px < G::HROWS * HPITCH && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-                            const unsigned off = ok ? (unsigned)(((b * a.Hin + iy) * a.Win + ix) * a.Cin + ck * EPC) * (unsigned)sizeof(T) : OOB;
-                            if (ok) aok |= 1u << i;
-                            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, off, 0, 0);
+                    for (int i = g * UPS; i < (g + 1) * UPS && i < AIT; ++i) {
+                        const int px = (ptid >> 3) + NA * 8 * i;
+                        if (px < G::HROWS * HPITCH) {
+                            // padding / overhang units arrive as zeros and must stay zero: the activation applies to real pixels only
+                            const bool real = a_off(i) != OOB && (chunk + 1) * CKE + ck * EPC < a.Cin;
+                            u32x4 o = areg[i];
+                            if (gn && real) o = gk.template apply<true>(areg[i]);
+                            *(u32x4*)(Ad + px * 128 + (((ck ^ (px >> 1)) & 7) << 4)) = o;
                         }
-                    } else {
-#pragma unroll
-                        for (int i = (g - 1) * UPS; i < g * UPS && i < AIT; ++i) {
-                            const int px = (ptid >> 3) + 16 * i;
-                            if (px < G::HROWS * HPITCH) {
-                                u32x4 o = areg[i];
-                                if (((aok >> i) & 1u) && gn) o = gk.template apply<true>(areg[i]);
-                                *(u32x4*)(Ad + px * 128 + (((ck ^ (px >> 1)) & 7) << 4)) = o;
-                            }
-                        }
+                        a_req(chunk + 2, i);
                     }
+                    if (g == NSPC - 1) gk = gk_next;
                 }
                 __syncthreads();
             }
         }
         stamp(2);
-        if (do_epi) {
-            epi_init();
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) { if (pass > 0) __syncthreads(); epi_pass(pass); }
-        }
+        if (do_epi) { epi_init(); epi_all(); }
         stamp(3);
     } else if (wave >= 4) {
-        // ------------------------------------------------------------------ B producers (2 waves): weights of the NEXT stage
-        // Requested at the start of the current stage, written to the other stage buffer before its barrier (L2 latency
-        // is covered by the stage's TPS*MF*NF*4 MFMAs).
+        // ------------------------------------------------------------------ B producers (NB waves): weights, ONE STAGE AHEAD IN REGISTERS
+        // During stage s these waves write stage s+1 (requested a whole stage earlier) into the other stage buffer and
+        // re-request the same registers for stage s+2.
         const int ptid = tid - 256;
-        constexpr int BU = BN * 8 / 128;                           // units per thread per tap
+        constexpr int BU = BN * 8 / (NB * 64);                     // units per thread per tap
         unsigned boff[BU];
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
-            const int idx = ptid + 128 * u;
+            const int idx = ptid + NB * 64 * u;
             boff[u] = (unsigned)(((size_t)(n0 + (idx >> 3)) * a.Cin_pad * sizeof(T)) + (idx & 7) * 16);
         }
+        u32x4 bset[TPS][BU];
+        // stage -> (chunk, tap group); requests past the end re-read the last stage (harmless, keeps the stream branch-free)
+        auto b_req = [&](int chunk, int g, int tt) __attribute__((always_inline)) {
+            const int c = chunk < a.nchunk ? chunk : a.nchunk - 1;
+            const auto srd = w_srd(g * TPS + tt, c);
+#pragma unroll
+            for (int u = 0; u < BU; ++u) bset[tt][u] = __builtin_amdgcn_raw_buffer_load_b128(srd, boff[u], 0, 0);
+        };
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) b_req(NSPC > 1 ? 0 : 1, NSPC > 1 ? 1 : 0, tt);       // stage 1
         __syncthreads();                                           // prologue tiles visible
         stamp(1);
         int stage = 0;
+        const int n_stage = a.nchunk * NSPC;
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
 #pragma unroll
             for (int g = 0; g < NSPC; ++g, ++stage) {
-                const int nchunk_ = (g + 1 < NSPC) ? chunk : chunk + 1;    // chunk / tap group of stage+1
-                const int ng = (g + 1 < NSPC) ? g + 1 : 0;
-                if (nchunk_ < a.nchunk && !(a.dbg & 2)) {
-                    u32x4 breg[TPS][BU];
+                constexpr int dummy = 0; (void)dummy;
+                const bool wr = stage + 1 < n_stage && !(a.dbg & 2);
+                unsigned char* const Bd = Bs + ((stage + 1) & 1) * L::B_BYTES;
 #pragma unroll
-                    for (int tt = 0; tt < TPS; ++tt) {
-                        const auto srd = w_srd(ng * TPS + tt, nchunk_);
-#pragma unroll
-                        for (int u = 0; u < BU; ++u) breg[tt][u] = __builtin_amdgcn_raw_buffer_load_b128(srd, boff[u], 0, 0);
-                    }
-                    unsigned char* const Bd = Bs + ((stage + 1) & 1) * L::B_BYTES;
-#pragma unroll
-                    for (int tt = 0; tt < TPS; ++tt)
+                for (int tt = 0; tt < TPS; ++tt) {
+                    if (wr) {
 #pragma unroll
                         for (int u = 0; u < BU; ++u) {
-                            const int idx = ptid + 128 * u, n = idx >> 3, ckb = idx & 7;
-                            *(u32x4*)(Bd + tt * L::BT_BYTES + n * 128 + (((ckb ^ (n >> 1)) & 7) << 4)) = breg[tt][u];
+                            const int idx = ptid + NB * 64 * u, n = idx >> 3, ckb = idx & 7;
+                            *(u32x4*)(Bd + tt * L::BT_BYTES + n * 128 + (((ckb ^ (n >> 1)) & 7) << 4)) = bset[tt][u];
                         }
+                    }
+                    b_req(chunk + (g + 2) / NSPC, (g + 2) % NSPC, tt);                         // stage + 2
                 }
                 __syncthreads();
             }
         }
         stamp(2);
-        if (do_epi) {
-            epi_init();
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) { if (pass > 0) __syncthreads(); epi_pass(pass); }
-        }
+        if (do_epi) { epi_init(); epi_all(); }
         stamp(3);
     } else {
         // ------------------------------------------------------------------ consumers (4 waves): ds_read_b128 + MFMA only
@@ -382,23 +398,18 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
         if (do_epi) {
             epi_init();
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                if (pass > 0) __syncthreads();                      // previous pass finished reading Cs
+            for (int i = 0; i < MF; ++i) {
+                const int row = wm * MF + i;                        // tile row of this fragment -> pass row/4, rows (row&3)*32..
+                float* const cst = Cs + (row / 4) * (L::CS1_BYTES / 4);
 #pragma unroll
-                for (int i = 0; i < MF; ++i) {
-                    const int row = wm * MF + i;                    // tile row of this fragment
-                    if (row / 4 == pass) {
+                for (int j = 0; j < NF; ++j)
 #pragma unroll
-                        for (int j = 0; j < NF; ++j)
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) {
-                                const int m = (row & 3) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                                Cs[m * CP + (wn * NF + j) * 32 + r] = acc[i][j][q];
-                            }
+                    for (int q = 0; q < 16; ++q) {
+                        const int m = (row & 3) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        cst[m * CP + (wn * NF + j) * 32 + r] = acc[i][j][q];
                     }
-                }
-                epi_pass(pass);
             }
+            epi_all();
         }
         stamp(3);
     }

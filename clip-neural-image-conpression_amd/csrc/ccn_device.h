@@ -65,9 +65,15 @@ template <> __device__ __forceinline__ void mfma16<__bf16>(f32x16& acc, const u3
 template <typename T> struct GnCoef;
 template <> struct GnCoef<float> {
     float a[4], c[4];
+    // vector loads issued together, ONE branch (a per-element select makes hipcc wait for each load in turn)
     __device__ __forceinline__ void load(const float2* ab, bool valid) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float2 v = valid ? ab[e] : make_float2(1.f, 0.f); a[e] = v.x; c[e] = v.y; }
+        for (int e = 0; e < 4; ++e) { a[e] = 1.f; c[e] = 0.f; }
+        if (valid) {
+            const f32x4 v0 = *(const f32x4*)ab, v1 = *(const f32x4*)(ab + 2);
+            a[0] = v0[0]; c[0] = v0[1]; a[1] = v0[2]; c[1] = v0[3];
+            a[2] = v1[0]; c[2] = v1[1]; a[3] = v1[2]; c[3] = v1[3];
+        }
     }
     template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
         float v[4];
@@ -85,10 +91,16 @@ template <> struct GnCoef<__bf16> {
     f32x2 a[4], c[4], an[4], cn[4];
     __device__ __forceinline__ void load(const float2* ab, bool valid) {
         const float nl2e = -1.4426950408889634f;
+        f32x4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f32x4{1.f, 0.f, 1.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = *(const f32x4*)(ab + 2 * e);        // 4 x 16 B, all in flight together
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float2 v0 = valid ? ab[2 * e] : make_float2(1.f, 0.f), v1 = valid ? ab[2 * e + 1] : make_float2(1.f, 0.f);
-            a[e] = f32x2{v0.x, v1.x}; c[e] = f32x2{v0.y, v1.y};
+            a[e] = f32x2{v[e][0], v[e][2]}; c[e] = f32x2{v[e][1], v[e][3]};
             an[e] = a[e] * nl2e; cn[e] = c[e] * nl2e;
         }
     }

@@ -57,6 +57,11 @@ bool conv_ws_supported(int kind, int bn);
 hipError_t conv_ws_prepare();
 hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s);
 
+// GroupNorm-apply + SiLU as its own pass (NHWC T -> NHWC T).  Used in front of convs whose input is re-staged by
+// several N tiles (Cout >= 256): the transform then runs once per element instead of once per (N tile x halo).
+bool conv_wants_preact(int kind, int bn, int n_nt);
+hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, int B, int HW, int C, hipStream_t s);
+
 // ---- GroupNorm finalize: partial sums -> per-(b,channel) scale/shift --------------------------------
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C,
                               double count, const float* gamma, const float* beta, float eps,

@@ -412,9 +412,11 @@ bool conv_ws_enabled()
 int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt)
 {
     if (!conv_ws_enabled() || !conv_ws_supported(kind, bn)) return 4;
-    // 8-row tiles halve the weight traffic and the halo overhead; keep >= 2 workgroups per CU
+    // 8-row tiles halve the weight traffic through L2 and LDS (the 4-row tile is LDS-bandwidth bound: 1 KB of
+    // fragment reads per MFMA plus 32 B/clk of weight ds_writes) and cut the halo overhead; keep every CU busy
     const long blocks8 = (long)B * ((MH + 7) / 8) * ((MW + 31) / 32) * npar * n_nt;
-    return blocks8 >= 512 ? 8 : 4;
+    static const long min8 = getenv("CCN_MIN8") ? atol(getenv("CCN_MIN8")) : 256;
+    return blocks8 >= min8 ? 8 : 4;
 }
 
 hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream_t s)
@@ -429,6 +431,52 @@ hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream
     const conv_fn_t fn = pick(dtype, kind, bn);
     const unsigned grid = (unsigned)(a.B * a.n_ty * a.n_tx * a.npar * a.n_nt);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), conv_lds_bytes(dtype, kind, bn), s, a);
+    return hipGetLastError();
+}
+
+// ---- GroupNorm-apply + SiLU pre-pass ----------------------------------------------------------------------
+bool conv_wants_preact(int kind, int bn, int n_nt)
+{
+    static const int mode = getenv("CCN_PREACT") ? atoi(getenv("CCN_PREACT")) : 1;    // 0 never, 1 when n_nt >= 2, 2 always
+    if (!conv_ws_enabled() || !conv_ws_supported(kind, bn) || kind != KIND_C3S1) return false;
+    return mode == 2 || (mode == 1 && n_nt >= 2);   // (launch_gn_act needs C/EPC <= 256; wider layers keep the fused prologue)
+}
+
+// thread -> fixed 16-byte channel slice (coefficients loaded once) x 4 pixels, all four loads in flight together
+template <typename T>
+__global__ __launch_bounds__(256) void gn_act_kernel(const T* __restrict__ x, const float2* __restrict__ ab, T* __restrict__ y,
+                                                      int HW, int C)
+{
+    constexpr int EPC = Vec16<T>::EPC;
+    const int nsl = C / EPC;                         // 16-byte slices per pixel (<= 256)
+    const int pstep = 256 / nsl;                     // pixels covered by one pass of the block
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int sl = tid % nsl, pp = tid / nsl;
+    if (pp >= pstep) return;
+    const int p0 = blockIdx.x * 4 * pstep + pp;
+    GnCoef<T> gk;
+    gk.load(ab + (size_t)b * C + sl * EPC, true);
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k * pstep;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (p < HW) v[k] = *(const u32x4*)(x + ((size_t)b * HW + p) * C + sl * EPC);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k * pstep;
+        if (p < HW) *(u32x4*)(y + ((size_t)b * HW + p) * C + sl * EPC) = gk.template apply<true>(v[k]);
+    }
+}
+hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, int B, int HW, int C, hipStream_t s)
+{
+    const int epc = dtype == 0 ? 4 : 8, nsl = C / epc;
+    if (nsl > 256 || nsl <= 0) return hipErrorInvalidValue;
+    const int pstep = 256 / nsl;
+    const dim3 grid((HW + 4 * pstep - 1) / (4 * pstep), B);
+    if (dtype == 0) hipLaunchKernelGGL(gn_act_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ab, (float*)y, HW, C);
+    else hipLaunchKernelGGL(gn_act_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, ab, (__bf16*)y, HW, C);
     return hipGetLastError();
 }
 
