@@ -113,9 +113,18 @@ def main() -> None:
         dom = max(fams, key=lambda f: f["ms"])
         tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         flops_fwd, bytes_fwd = nat.algorithmic_work(B, S, S)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see
+        # tools/pmc_traffic.py); only valid for the workload it was collected on
+        traffic = None
+        pmc = REPO / "profiles" / "r01_pmc_traffic.json"
+        if pmc.exists() and args.dtype == "bf16" and (B, S, args.base, ch_mult) == (8, 256, 128, (1, 2, 2)):
+            pj = json.loads(pmc.read_text())
+            if pj.get("kernel_family") == dom["name"]:
+                traffic = round(pj["hbm_bytes_per_launch"])
         roofline = {
             "bound": "mfma", "kernel": dom["name"], "achieved": round(tfs, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-            "frac": round(tfs / PEAK[args.dtype], 4), "traffic": None,
+            "frac": round(tfs / PEAK[args.dtype], 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
             "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
             "algorithmic_gflop_per_launch": round(dom["flops"] / dom["calls"] / 1e9, 3),
             "kernel_hbm_gbs_algorithmic": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),

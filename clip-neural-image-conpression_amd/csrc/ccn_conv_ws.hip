@@ -84,8 +84,21 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     const int iy0 = my0 - 1, ix0 = mx0 - 1;
     // diagnostic stamps (a.stamps is null outside profiling runs): slot 0 entry, 1 prologue done, 2 loop done, 3 exit, per role
     auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0)) {
+            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8;
+            st[slot] = __builtin_amdgcn_s_memrealtime();
+            if (slot == 1) st[5] = __builtin_amdgcn_s_memtime();       // shader-clock stamps around the loop -> in-kernel clock
+            if (slot == 2) st[6] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    unsigned long long bar_wait = 0;      // diagnostic: shader cycles spent inside the loop's barriers
+    auto loop_barrier = [&]() __attribute__((always_inline)) {
+        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); __syncthreads(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
+        else __syncthreads();
+    };
+    auto stamp_wait = [&]() __attribute__((always_inline)) {
         if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0))
-            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 4 + slot] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8 + 4] = bar_wait;
     };
     stamp(0);
     const size_t wtap_bytes = (size_t)a.Cout_pad * a.Cin_pad * sizeof(T);      // one tap of the packed weights
@@ -275,10 +288,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                     }
                     if (g == NSPC - 1) gk = gk_next;
                 }
-                __syncthreads();
+                loop_barrier();
             }
         }
-        stamp(2);
+        stamp(2); stamp_wait();
         if (do_epi) { epi_init(); epi_all(); }
         stamp(3);
     } else if (wave >= 4) {
@@ -324,10 +337,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                     }
                     b_req(chunk + (g + 2) / NSPC, (g + 2) % NSPC, tt);                         // stage + 2
                 }
-                __syncthreads();
+                loop_barrier();
             }
         }
-        stamp(2);
+        stamp(2); stamp_wait();
         if (do_epi) { epi_init(); epi_all(); }
         stamp(3);
     } else {
@@ -366,7 +379,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                 const int b_off = 2 * L::A_BYTES + (stage & 1) * L::B_BYTES;
                 if (!(a.dbg & 4)) {
                     // fragments of step j+1 are requested before the MFMAs of step j (step = tap * 4 + kk)
-                    u32x4 av[2][MF], bv[2][NF];
+                    constexpr int PF = 1;                         // fragment prefetch distance in steps (2 measured no faster: the loop is LDS-bandwidth bound)
+                    constexpr int NSTEP = TPS * 4;
+                    u32x4 av[PF + 1][MF], bv[PF + 1][NF];
                     int abase[MF];
                     auto frag = [&](int j, u32x4* av_, u32x4* bv_) __attribute__((always_inline)) {
                         const int tt = j >> 2, kk = j & 3;
@@ -380,21 +395,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                         for (int jn = 0; jn < NF; ++jn)
                             bv_[jn] = *(const u32x4*)(smem + b_off + tt * L::BT_BYTES + (bbase[jn] ^ (kk << 5)));
                     };
-                    frag(0, av[0], bv[0]);
 #pragma unroll
-                    for (int j = 0; j < TPS * 4; ++j) {
-                        if (j + 1 < TPS * 4) frag(j + 1, av[(j + 1) & 1], bv[(j + 1) & 1]);
+                    for (int j = 0; j < PF && j < NSTEP; ++j) frag(j, av[j % (PF + 1)], bv[j % (PF + 1)]);
+#pragma unroll
+                    for (int j = 0; j < NSTEP; ++j) {
+                        if (j + PF < NSTEP) frag(j + PF, av[(j + PF) % (PF + 1)], bv[(j + PF) % (PF + 1)]);
+                        // pin the software pipeline: hipcc otherwise sinks these reads next to their use and every step
+                        // eats a full LDS round trip; pinned, the wait before step j's MFMAs is a counted lgkmcnt that
+                        // leaves the later steps' reads in flight
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
 #pragma unroll
-                            for (int jn = 0; jn < NF; ++jn) mfma16<T>(acc[i][jn], av[j & 1][i], bv[j & 1][jn]);
+                            for (int jn = 0; jn < NF; ++jn) mfma16<T>(acc[i][jn], av[j % (PF + 1)][i], bv[j % (PF + 1)][jn]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __syncthreads();
+                loop_barrier();
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        stamp(2);
+        stamp(2); stamp_wait();
         if (do_epi) {
             epi_init();
 #pragma unroll
@@ -497,12 +518,12 @@ static unsigned g_stamp_grid = 0;
 extern "C" int ccn_internal_dump_stamps(const char* path)
 {
     if (!g_stamps || !g_stamp_grid) return 1;
-    std::vector<unsigned long long> h((size_t)g_stamp_grid * 12);
+    std::vector<unsigned long long> h((size_t)g_stamp_grid * 24);
     if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     FILE* f = fopen(path, "w");
     if (!f) return 3;
     for (unsigned b = 0; b < g_stamp_grid; ++b) {
-        for (int k = 0; k < 12; ++k) fprintf(f, "%llu%c", h[(size_t)b * 12 + k], k == 11 ? '\n' : ' ');
+        for (int k = 0; k < 24; ++k) fprintf(f, "%llu%c", h[(size_t)b * 24 + k], k == 23 ? '\n' : ' ');
     }
     fclose(f);
     return 0;
@@ -515,7 +536,7 @@ hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s)
     if (env) {
         unsigned want = (unsigned)atoi(env), want_taps = strchr(env, ':') ? (unsigned)atoi(strchr(env, ':') + 1) : 9u;
         if (grid == want && (unsigned)a.ntaps == want_taps) {
-            if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)8192 * 12 * 8) != hipSuccess) return hipErrorOutOfMemory; }
+            if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)8192 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
             if (grid <= 8192) {
                 g_stamp_grid = grid;
                 ConvArgs d = a; d.stamps = g_stamps;
