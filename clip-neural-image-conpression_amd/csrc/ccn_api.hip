@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -71,6 +72,7 @@ struct TensorRef {
     int C = 0, H = 0, W = 0;
     float2* part = nullptr;      // GroupNorm partial sums written by the producer
     int n_sp = 0, n_nt = 0, bn = 0;
+    std::shared_ptr<ConvArgs> prod;   // launch arguments of the producing conv (patched when its GroupNorm finalize is fused in)
 };
 
 struct StepCtx {
@@ -98,6 +100,8 @@ struct Bump {
     void* take(size_t bytes) { off = align_up(off, 256); void* p = measure ? nullptr : base + off; off += bytes; return p; }
 };
 
+constexpr int kMaxNorms = 128;
+
 struct GraphEntry {
     int steps = 0;
     std::vector<int32_t> ts;
@@ -114,6 +118,8 @@ struct Plan {
     int32_t* ts_dev = nullptr;
     float *temb = nullptr, *t1 = nullptr, *tp = nullptr, *zp = nullptr, *film = nullptr;
     float *zbuf = nullptr, *xstate = nullptr;
+    unsigned* counters = nullptr;        // arrival counters of the fused GroupNorm finalizes, [kMaxNorms][B], zero at rest
+    int n_counters = 0;
     std::vector<int32_t> ts_keep;        // host copy of the last timestep table (source of the async upload)
     std::vector<Launch> ops;             // one UNet evaluation (+ DDIM update in the head)
     std::map<std::string, TensorRef> named;
@@ -343,7 +349,8 @@ struct PlanBuilder {
               const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
     {
         const ConvGeom g = conv_geom(cw, B, in.H, in.W);
-        ConvArgs a{};
+        std::shared_ptr<ConvArgs> ap(new ConvArgs());
+        ConvArgs& a = *ap;
         a.in = in.p; a.w = cw.w; a.bias = cw.bias; a.out = out.p;
         a.gn_ab = gn_ab; a.film = nullptr; a.res = res ? res->p : nullptr;
         a.B = B; a.Hin = in.H; a.Win = in.W; a.Cin = cw.Cin; a.Cin_pad = cw.Cin_pad;
@@ -362,6 +369,9 @@ struct PlanBuilder {
             out.n_sp = g.n_ty * g.n_tx * g.npar; out.n_nt = g.n_nt; out.bn = cw.BN;
         }
         a.part = out.part;
+        a.bn = cw.BN;
+        a.fin_blocks = g.n_ty * g.n_tx * g.npar * g.n_nt;
+        if (want_part) out.prod = ap;
         const double macs = (double)B * g.Hout * g.Wout * cw.Cout * (double)(cw.kind == KIND_CT4 ? 4 : (cw.kind == KIND_STEM ? 9 : 9)) * cw.Cin;
         double bytes = ((double)B * in.H * in.W * cw.Cin + (double)B * g.Hout * g.Wout * cw.Cout + (res ? (double)B * g.Hout * g.Wout * cw.Cout : 0.0)
                         + (double)(cw.kind == KIND_CT4 ? 16 : 9) * cw.Cin * cw.Cout) * h->elem;
@@ -373,7 +383,7 @@ struct PlanBuilder {
         const int Bc = B;
         Launch L{family, 2.0 * macs, bytes, nullptr};
         L.fn = [=](hipStream_t s, const StepCtx& c) -> hipError_t {
-            ConvArgs k = a;
+            ConvArgs k = *ap;                                 // read at launch time: gn() may have fused its finalize in
             if (film_off >= 0) k.film = film_tab + (size_t)c.step * Bc * F + film_off;
             if (is_stem) k.in = c.x_in;
             if (is_head) {
@@ -391,6 +401,17 @@ struct PlanBuilder {
         float2* ab = new_ab(t.C);
         const int G = groups_for(t.C), cpg = t.C / G;
         const double count = (double)cpg * t.H * t.W;
+        // measured slower than the 5 us finalize launch it removes (every workgroup drains its stores and pays an atomic
+        // round trip before exiting): 50.4 vs 52.1 img/s at C2, so opt-in only
+        static const bool fuse = getenv("CCN_FUSED_FINALIZE") != nullptr;
+        if (fuse && t.prod && plan->counters && plan->n_counters < kMaxNorms) {
+            // the producing conv's last workgroup per sample does the finalize (no launch, no kernel boundary)
+            ConvArgs& pa = *t.prod;
+            pa.fin_counter = plan->counters + (size_t)plan->n_counters * B;
+            plan->n_counters++;
+            pa.fin_gamma = n.gamma; pa.fin_beta = n.beta; pa.fin_ab = ab; pa.fin_count = count;
+            return ab;
+        }
         const float2* part = t.part; const int n_sp = t.n_sp, n_nt = t.n_nt, bn = t.bn, C = t.C, Bc = B;
         const float* gamma = n.gamma; const float* beta = n.beta;
         Launch L{F_GNF, 0.0, (double)B * G * n_sp * n_nt * 8.0 + (double)B * C * 8.0, nullptr};
@@ -445,6 +466,8 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
     plan->film = (float*)pb.bump.take((size_t)FR * h->F * 4);
     plan->zbuf = (float*)pb.bump.take((size_t)B * c.z_dim * 4);
     plan->xstate = (float*)pb.bump.take((size_t)B * c.img_ch * H * W * 4);
+    plan->counters = (unsigned*)pb.bump.take((size_t)kMaxNorms * B * 4);
+    plan->n_counters = 0;
 
     plan->ops.clear(); plan->named.clear();
     TensorRef img; img.C = c.img_ch; img.H = H; img.W = W;     // NCHW fp32, pointer supplied per call
@@ -514,6 +537,7 @@ int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t w
     int rc = build_plan(h, p.get(), ws, false);
     if (rc) return rc;
     if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(p->bytes));
+    HIPCHK(hipMemset(p->counters, 0, (size_t)kMaxNorms * B * 4));          // arrival counters start (and are left) at zero
     if (h->plans.size() >= 8) h->plans.erase(h->plans.begin());
     *out = p.get();
     h->plans.push_back(std::move(p));
@@ -877,6 +901,9 @@ int ccn_resblock_forward(ccn_handle_t h, const char* prefix, const float* x_dev,
     PlanBuilder pb(h, &tmp, workspace_dev, false);
     pb.film_stride = 2 * r->C;                                    // dense (B, 2C) table: [scale | shift] of this block only
     tmp.film = (float*)pb.bump.take((size_t)B * 2 * r->C * 4);
+    tmp.counters = (unsigned*)pb.bump.take((size_t)8 * B * 4);
+    tmp.n_counters = 0;
+    HIPCHK(hipMemsetAsync(tmp.counters, 0, (size_t)8 * B * 4, s));
     TensorRef x = pb.new_tensor(r->C, H, W);
     const int G = pb.groups_for(r->C), cpg = r->C / G;
     int nslot = (H * W + 1023) / 1024; if (nslot < 1) nslot = 1;

@@ -466,9 +466,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                 float t1 = 0.f, t2 = 0.f;
                 for (int c = clo; c < chi; ++c) { t1 += chs[(c - n0) * 2]; t2 += chs[(c - n0) * 2 + 1]; }
                 const int slot = (((ty * a.n_tx + tx) * a.npar + par) * a.n_nt) + nt;
-                a.part[(size_t)(b * a.G + g) * a.nslot + slot] = make_float2(t1, t2);
+                part_store(a.part + (size_t)(b * a.G + g) * a.nslot + slot, t1, t2);
             }
         }
+        if (a.fin_counter) gn_fused_finalize<512>(a, b, (unsigned*)red, tid);
     }
 }
 

@@ -122,4 +122,69 @@ template <> struct GnCoef<__bf16> {
     }
 };
 
+
+// ---- GroupNorm partial sums: write-through publish + last-arriver finalize ---------------------------------------------
+// Hand-off between workgroups of ONE launch, placement-independent (cdna_hip_programming.md Guideline 16, R1 with an
+// arrival counter): every partial is ONE 8-byte agent-scope (sc1, write-through) store; every storing wave drains its
+// stores; workgroup barrier; one lane adds to the sample's counter; the workgroup whose add returns fin_blocks-1 is the
+// last one: one agent-scope acquire, barrier, sc1 loads of every partial of that sample in a fixed order.
+__device__ __forceinline__ void part_store(float2* p, float s1, float s2)
+{
+    const unsigned long long v = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 part_load(const float2* p)
+{
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// scale/shift of every channel of group g of sample b from its partial sums; one wave per group, fixed summation order
+__device__ __forceinline__ void gn_reduce_group(const float2* part, int b, int g, int G, int nslot, int n_nt, int bn, int cpg, int C,
+                                                double count, const float* gamma, const float* beta, float eps, float2* ab, int lane)
+{
+    const int jlo = (g * cpg) / bn, jhi = ((g + 1) * cpg - 1) / bn, nj = jhi - jlo + 1;
+    const int n_sp = nslot / n_nt, ne = n_sp * nj;
+    const float2* base = part + (size_t)(b * G + g) * nslot;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = lane; e < ne; e += 64) {
+        const int sp = e / nj, j = jlo + (e - sp * nj);
+        const float2 v = part_load(base + (size_t)sp * n_nt + j);
+        s1 += (double)v.x; s2 += (double)v.y;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const double sc = (double)gamma[c] * rstd;
+        ab[(size_t)b * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+    }
+}
+
+// call with ALL threads of the workgroup after its part_store()s; `flag` is a free LDS word
+template <int NT>
+__device__ __forceinline__ void gn_fused_finalize(const ConvArgs& a, int b, unsigned* flag, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.fin_counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (old == (unsigned)a.fin_blocks - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int g = wave; g < a.G; g += NT / 64)
+        gn_reduce_group(a.part, b, g, a.G, a.nslot, a.n_nt, a.bn, a.cpg, a.Cout, a.fin_count, a.fin_gamma, a.fin_beta, 1e-5f, a.fin_ab, lane);
+    if (tid == 0) __hip_atomic_store(a.fin_counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
 }  // namespace ccn

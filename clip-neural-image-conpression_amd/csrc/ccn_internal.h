@@ -24,6 +24,14 @@ struct ConvArgs {
     const float* film;      // epilogue FiLM for this step: [B][film_bstride], s at [n], shift at [Cout+n]; or null
     const void* res;        // epilogue residual / skip, NHWC T like out; or null
     float2* part;           // epilogue GroupNorm partial sums [B][G][nslot] (sum, sum of squares); or null
+    // fused GroupNorm finalize: the last workgroup of a sample to arrive reduces that sample's partial sums and writes the
+    // consuming norm's per-channel (scale, shift); null fin_counter = separate gn_finalize launch
+    unsigned* fin_counter;  // [B] arrival counters, zero between launches
+    const float* fin_gamma; const float* fin_beta;
+    float2* fin_ab;         // [B][Cout]
+    double fin_count;       // elements per (sample, group)
+    int fin_blocks;         // workgroups per sample
+    int bn;                 // N-tile width of this launch
     float* x_state;         // head: DDIM state, NCHW fp32, updated in place when do_ddim
     float* eps_out;         // head: eps NCHW fp32, or null
     float c0, c1, c2, c3;   // head: DDIM coefficients

@@ -330,9 +330,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                     float t1 = 0.f, t2 = 0.f;
                     for (int c = clo; c < chi; ++c) { t1 += chs[(c - n0) * 2]; t2 += chs[(c - n0) * 2 + 1]; }
                     const int slot = (((ty * a.n_tx + tx) * a.npar + par) * a.n_nt) + nt;
-                    a.part[(size_t)(b * a.G + g) * a.nslot + slot] = make_float2(t1, t2);
+                    part_store(a.part + (size_t)(b * a.G + g) * a.nslot + slot, t1, t2);
                 }
             }
+            if (a.fin_counter) gn_fused_finalize<256>(a, b, (unsigned*)red, tid);
         }
     }
 }
@@ -485,25 +486,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
                                                           int cpg, int C, double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float2* __restrict__ ab)
 {
-    const int bg = blockIdx.x, b = bg / G, g = bg % G, lane = threadIdx.x;
-    const int jlo = (g * cpg) / bn, jhi = ((g + 1) * cpg - 1) / bn;
-    const size_t base = (size_t)bg * n_sp * n_nt;
-    double s1 = 0.0, s2 = 0.0;
-    for (int sp = lane; sp < n_sp; sp += 64)
-        for (int j = jlo; j <= jhi; ++j) {
-            const float2 v = part[base + (size_t)sp * n_nt + j];
-            s1 += (double)v.x; s2 += (double)v.y;
-        }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-        const double sc = (double)gamma[c] * rstd;
-        ab[(size_t)b * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
-    }
+    const int bg = blockIdx.x;
+    gn_reduce_group(part, bg / G, bg % G, G, n_sp * n_nt, n_nt, bn, cpg, C, count, gamma, beta, eps, ab, threadIdx.x);
 }
 
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C, double count,
