@@ -1,20 +1,12 @@
-// Warp-specialised implicit-GEMM convolution for the stride-1 3x3 convs and the ConvTranspose parities (the
-// 3x3-s1 ResBlock convs are 87 % of the path's FLOPs).
+// LDS-DMA variant of the warp-specialised implicit-GEMM convolution (see ccn_conv_ws.hip for the common structure).
 //
-// One workgroup = 8 waves on one CU:
-//   waves 0-3  consumers: nothing but ds_read_b128 + MFMA over the staged tiles (2x2 waves, MF x NF fragments each)
-//   waves 4-7  producers: run one pipeline step ahead -- global loads of the next input-halo chunk and weight
-//              stage, the GroupNorm-apply + SiLU transform (VALU, transcendental-heavy), ds_write into the
-//              *other* LDS buffer
-// so the VALU prologue fusion and the staging traffic overlap the matrix pipe instead of alternating with it
-// (MFMA and VALU are separate pipes; a wave issues in order, so the overlap has to come from different waves).
-// Both operands are double buffered; ONE workgroup barrier per (Cin-chunk, tap) iteration orders everything:
-//   iteration it:  consumers read A[c&1], B[it&1];  producers write B[(it+1)&1] and a slice of A[(c+1)&1]
-// The epilogue (accumulators -> LDS fp32 tile -> bias / FiLM / residual -> coalesced 16-B NHWC rows + the next
-// GroupNorm's partial sums) is shared by all 8 waves, 128 pixels per pass, with the residual rows prefetched
-// into registers before the pass barrier.
-//
-// Tile: TH x 32 output-space pixels (TH = 4*MF/2: 4 or 8 rows of 32) x BN = 64*NF output channels.
+// Difference: the weight (B) operand never passes through VGPRs or ds_write.  The four consumer waves issue
+// `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per wave instruction) for the stage TWO ahead into a ring of three
+// 16 KB stage buffers, between their MFMAs; a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (never __syncthreads,
+// which would drain the DMA queue) publishes stage s+1 while stage s+2 stays in flight.  That removes the
+// ds_write_b128 traffic of the weights (32 B/clk/CU at full MFMA rate against a ~79 B/clk store path) from the LDS
+// port the fragment reads compete for, and frees all four producer waves for the input operand (GroupNorm + SiLU).
+// The DMA destination is lane-linear (base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE offset.
 #include "ccn_device.h"
 #include <cstdio>
 #include <cstdlib>
@@ -30,11 +22,11 @@ template <int TH> struct WsGeom {
     static constexpr int A_BYTES = HROWS * HPITCH * 128;
     static constexpr int AU = HROWS * HPITCH * 8;            // 16-byte units per chunk
 };
-template <int TH, int BN, int TPS> struct WsLds {
+template <int TH, int BN, int NBUF> struct WsLds {
     static constexpr int A_BYTES = WsGeom<TH>::A_BYTES;
-    static constexpr int BT_BYTES = BN * 128;                // one tap of one stage
-    static constexpr int B_BYTES = TPS * BT_BYTES;           // one stage
-    static constexpr int LOOP = 2 * A_BYTES + 2 * B_BYTES;
+    static constexpr int BT_BYTES = BN * 128;                // one tap = one stage
+    static constexpr int B_BYTES = BT_BYTES;
+    static constexpr int LOOP = 2 * A_BYTES + NBUF * B_BYTES;
     static constexpr int CP = BN + 4;
     static constexpr int CS1_BYTES = 128 * CP * 4;           // fp32 epilogue tile of one 128-pixel pass
     static constexpr int CS_BYTES = (TH / 4) * CS1_BYTES;    // all passes at once: one barrier for the whole epilogue
@@ -44,26 +36,26 @@ template <int TH, int BN, int TPS> struct WsLds {
 
 }  // namespace
 
-template <typename T, int MF, int NF, int NTAPS, int TPS>
-__global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
+template <typename T, int MF, int NF, int NTAPS>
+__global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a)
 {
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * MF;                 // tile rows of 32 pixels
     constexpr int BN = WN * NF * 32;
     constexpr int EPC = Vec16<T>::EPC;
     constexpr int CKE = 8 * EPC;
+    constexpr int TPS = 1;                      // one tap per stage
+    constexpr int NBUF = 3;                     // weight stage ring
     constexpr int NSPC = NTAPS / TPS;           // stages (barriers) per Cin chunk
-    // producer waves 4..7: NB weight waves then NA input waves.  8-row tiles move 16 KB of weights per stage (one wave
-    // keeps up) and carry the GroupNorm+SiLU VALU work on 1.7x more input, so they get 3 input waves; 4-row tiles 2 + 2.
-    constexpr int NB = MF == 4 ? 1 : 2, NA = 4 - NB;
-    constexpr int A0 = 4 + NB;                  // first A-producer wave
+    constexpr int NA = 4;                       // all four producer waves stage the input operand
+    constexpr int A0 = 4;                       // first A-producer wave
     static_assert(NSPC * TPS == NTAPS && NSPC >= 2, "taps must split evenly into >= 2 stages per chunk");
     using G = WsGeom<TH>;
-    using L = WsLds<TH, BN, TPS>;
+    using L = WsLds<TH, BN, NBUF>;
     constexpr int HPITCH = G::HPITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const As = smem;                         // 2 chunk buffers
-    unsigned char* const Bs = smem + 2 * L::A_BYTES;        // 2 stage buffers of TPS taps
+    unsigned char* const Bs = smem + 2 * L::A_BYTES;        // ring of NBUF one-tap stage buffers
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -84,21 +76,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     const int iy0 = my0 - 1, ix0 = mx0 - 1;
     // diagnostic stamps (a.stamps is null outside profiling runs): slot 0 entry, 1 prologue done, 2 loop done, 3 exit, per role
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0)) {
-            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8;
+        if (a.stamps && lane == 0 && (wave == 0 || wave == A0)) {
+            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8;
             st[slot] = __builtin_amdgcn_s_memrealtime();
             if (slot == 1) st[5] = __builtin_amdgcn_s_memtime();       // shader-clock stamps around the loop -> in-kernel clock
             if (slot == 2) st[6] = __builtin_amdgcn_s_memtime();
         }
     };
     unsigned long long bar_wait = 0;      // diagnostic: shader cycles spent inside the loop's barriers
+    // raw barrier: drain only this wave's LDS operations; in-flight buffer loads (register prefetch, LDS-DMA) survive it
+    auto raw_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     auto loop_barrier = [&]() __attribute__((always_inline)) {
-        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); __syncthreads(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
-        else __syncthreads();
+        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
+        else raw_barrier();
     };
     auto stamp_wait = [&]() __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0))
-            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8 + 4] = bar_wait;
+        if (a.stamps && lane == 0 && (wave == 0 || wave == A0))
+            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8 + 4] = bar_wait;
     };
     stamp(0);
     const size_t wtap_bytes = (size_t)a.Cout_pad * a.Cin_pad * sizeof(T);      // one tap of the packed weights
@@ -116,7 +114,28 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                                                  0, (unsigned)wtap_bytes, 0x00020000);
     };
 
-    // ------------------------------------------------------------------ prologue: chunk 0 and stage 0 by all 512 threads
+    // weight stage `stage` (tap g of chunk c) -> ring slot stage % NBUF, by the four consumer waves: BN/8 one-KiB pieces
+    // (8 rows of 128 B each), piece k = wave*PPW + q; lane l lands at row 8k + (l>>3), physical chunk l&7, and therefore
+    // fetches logical chunk (l&7) ^ ((row>>1)&7) of that row
+    constexpr int PPW = BN / 8 / 4;                           // pieces per consumer wave per stage
+    auto b_dma = [&](int chunk, int g, int slot) __attribute__((always_inline)) {
+        const int c = chunk < a.nchunk ? chunk : a.nchunk - 1;
+        const auto srd = w_srd(g, c);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int k = wave * PPW + q;
+            const int row = 8 * k + (lane >> 3);
+            const unsigned voff = (unsigned)((size_t)(n0 + row) * a.Cin_pad * sizeof(T)) + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass cannot type-check the LDS-pointer cast and would drop the kernel stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(Bs + slot * L::B_BYTES + k * 1024),
+                                                     16, voff, 0, 0, 0);
+#else
+            (void)voff; (void)srd;
+#endif
+        }
+    };
+
+    // ------------------------------------------------------------------ prologue: chunk 0 by all 512 threads, weight stages 0 and 1 by DMA
     {
         const int ck = tid & 7;
         GnCoef<T> gk;
@@ -136,13 +155,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
             raw[i] = __builtin_amdgcn_raw_buffer_load_b128(srd0, off, 0, 0);
             if (ok) okm |= 1u << i;
         }
-        constexpr int BU0 = TPS * BN * 8 / 512;
-        u32x4 b0[BU0];
-#pragma unroll
-        for (int u = 0; u < BU0; ++u) {
-            const int idx = tid + 512 * u, tt = idx / (BN * 8), rem = idx - tt * (BN * 8), n = rem >> 3, ckb = rem & 7;
-            b0[u] = __builtin_amdgcn_raw_buffer_load_b128(w_srd(tt, 0), (unsigned)(((size_t)(n0 + n) * a.Cin_pad) * sizeof(T) + ckb * 16), 0, 0);
-        }
+        if (wave < 4) { b_dma(0, 0, 0); b_dma(NSPC > 1 ? 0 : 1, NSPC > 1 ? 1 : 0, 1); }
 #pragma unroll
         for (int i = 0; i < PIT; ++i) {
             const int px = (tid >> 3) + 64 * i;
@@ -152,11 +165,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
                 *(u32x4*)(As + px * 128 + (((ck ^ (px >> 1)) & 7) << 4)) = o;
             }
         }
-#pragma unroll
-        for (int u = 0; u < BU0; ++u) {
-            const int idx = tid + 512 * u, tt = idx / (BN * 8), rem = idx - tt * (BN * 8), n = rem >> 3, ckb = rem & 7;
-            *(u32x4*)(Bs + tt * L::BT_BYTES + n * 128 + (((ckb ^ (n >> 1)) & 7) << 4)) = b0[u];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk 0 consumed above; both weight stages have landed
     }
 
     // ------------------------------------------------------------------ epilogue pieces (used by every role after its loop)
@@ -294,55 +303,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
         stamp(2); stamp_wait();
         if (do_epi) { epi_init(); epi_all(); }
         stamp(3);
-    } else if (wave >= 4) {
-        // ------------------------------------------------------------------ B producers (NB waves): weights, ONE STAGE AHEAD IN REGISTERS
-        // During stage s these waves write stage s+1 (requested a whole stage earlier) into the other stage buffer and
-        // re-request the same registers for stage s+2.
-        const int ptid = tid - 256;
-        constexpr int BU = BN * 8 / (NB * 64);                     // units per thread per tap
-        unsigned boff[BU];
-#pragma unroll
-        for (int u = 0; u < BU; ++u) {
-            const int idx = ptid + NB * 64 * u;
-            boff[u] = (unsigned)(((size_t)(n0 + (idx >> 3)) * a.Cin_pad * sizeof(T)) + (idx & 7) * 16);
-        }
-        u32x4 bset[TPS][BU];
-        // stage -> (chunk, tap group); requests past the end re-read the last stage (harmless, keeps the stream branch-free)
-        auto b_req = [&](int chunk, int g, int tt) __attribute__((always_inline)) {
-            const int c = chunk < a.nchunk ? chunk : a.nchunk - 1;
-            const auto srd = w_srd(g * TPS + tt, c);
-#pragma unroll
-            for (int u = 0; u < BU; ++u) bset[tt][u] = __builtin_amdgcn_raw_buffer_load_b128(srd, boff[u], 0, 0);
-        };
-#pragma unroll
-        for (int tt = 0; tt < TPS; ++tt) b_req(NSPC > 1 ? 0 : 1, NSPC > 1 ? 1 : 0, tt);       // stage 1
-        __syncthreads();                                           // prologue tiles visible
-        stamp(1);
-        int stage = 0;
-        const int n_stage = a.nchunk * NSPC;
-        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-#pragma unroll
-            for (int g = 0; g < NSPC; ++g, ++stage) {
-                constexpr int dummy = 0; (void)dummy;
-                const bool wr = stage + 1 < n_stage && !(a.dbg & 2);
-                unsigned char* const Bd = Bs + ((stage + 1) & 1) * L::B_BYTES;
-#pragma unroll
-                for (int tt = 0; tt < TPS; ++tt) {
-                    if (wr) {
-#pragma unroll
-                        for (int u = 0; u < BU; ++u) {
-                            const int idx = ptid + NB * 64 * u, n = idx >> 3, ckb = idx & 7;
-                            *(u32x4*)(Bd + tt * L::BT_BYTES + n * 128 + (((ckb ^ (n >> 1)) & 7) << 4)) = bset[tt][u];
-                        }
-                    }
-                    b_req(chunk + (g + 2) / NSPC, (g + 2) % NSPC, tt);                         // stage + 2
-                }
-                loop_barrier();
-            }
-        }
-        stamp(2); stamp_wait();
-        if (do_epi) { epi_init(); epi_all(); }
-        stamp(3);
     } else {
         // ------------------------------------------------------------------ consumers (4 waves): ds_read_b128 + MFMA only
         __builtin_amdgcn_s_setprio(2);
@@ -376,10 +336,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
             for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop (no hoist + spill)
 #pragma unroll
             for (int g = 0; g < NSPC; ++g, ++stage) {
-                const int b_off = 2 * L::A_BYTES + (stage & 1) * L::B_BYTES;
+                const int b_off = 2 * L::A_BYTES + (stage % NBUF) * L::B_BYTES;
                 {
                     // fragments of step j+1 are requested before the MFMAs of step j (step = tap * 4 + kk)
-                    constexpr int PF = 1;                         // fragment prefetch distance in steps (2 measured no faster: the loop is LDS-bandwidth bound)
+                    constexpr int PF = 1;
                     constexpr int NSTEP = TPS * 4;
                     u32x4 av[PF + 1][MF], bv[PF + 1][NF];
                     int abase[MF];
@@ -400,28 +360,29 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
 #pragma unroll
                     for (int j = 0; j < NSTEP; ++j) {
                         __builtin_amdgcn_sched_barrier(0);
+                        if (j == 0) b_dma(chunk + (g + 2) / NSPC, (g + 2) % NSPC, (stage + 2) % NBUF);     // stage + 2, in the MFMA shadows
                         if (j + PF < NSTEP) frag(j + PF, av[(j + PF) % (PF + 1)], bv[(j + PF) % (PF + 1)]);
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
 #pragma unroll
                             for (int jn = 0; jn < NF; ++jn) mfma16<T>(acc[i][jn], av[j % (PF + 1)][i], bv[j % (PF + 1)][jn]);
-                        // An in-order wave that issues its MFMAs back to back leaves 24 of every 32 issue cycles unused and
-                        // then runs the next step's address math / ds_reads while the matrix pipe drains (a pure MFMA
-                        // stream measured 76 % of the pipe rate).  Interleave: one MFMA, then one LDS read and up to two
-                        // VALU of the NEXT step's fragment fetch in its shadow; the wait before this step's first MFMA is
-                        // then a counted lgkmcnt on reads issued a whole step ago.
+                        // one MFMA, then (first step of the stage) one LDS-DMA piece, one LDS read and up to two VALU in its shadow
 #pragma unroll
                         for (int m = 0; m < MF * NF; ++m) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                            if (j == 0 && m < PPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (DMA piece)
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
                             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // 2 VALU
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                // stage+1's pieces (issued one stage ago) must have landed; the PPW pieces just issued may stay in flight
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
                 loop_barrier();
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ring is about to be reused by the epilogue tile
         __builtin_amdgcn_s_setprio(0);
         stamp(2); stamp_wait();
         if (do_epi) {
@@ -482,79 +443,70 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-// 3x3 s1: 4-row tiles stage 3 taps per barrier, 8-row tiles 1 tap (LDS); ConvTranspose parities (4 taps): 2 / 1.
-typedef void (*ws_fn_t)(const ConvArgs);
+typedef void (*dma_fn_t)(const ConvArgs);
 
-template <typename T> static ws_fn_t pick_ws_t(int ntaps, int th, int bn)
+template <typename T> static dma_fn_t pick_dma_t(int ntaps, int th, int bn)
 {
     if (ntaps == 9) {
-        if (th == 8) return bn == 128 ? conv_ws_kernel<T, 4, 2, 9, 1> : conv_ws_kernel<T, 4, 1, 9, 1>;
-        return bn == 128 ? conv_ws_kernel<T, 2, 2, 9, 3> : conv_ws_kernel<T, 2, 1, 9, 3>;
+        if (th == 8) return bn == 128 ? conv_dma_kernel<T, 4, 2, 9> : conv_dma_kernel<T, 4, 1, 9>;
+        return bn == 128 ? conv_dma_kernel<T, 2, 2, 9> : conv_dma_kernel<T, 2, 1, 9>;
     }
-    if (th == 8) return bn == 128 ? conv_ws_kernel<T, 4, 2, 4, 1> : conv_ws_kernel<T, 4, 1, 4, 1>;
-    return bn == 128 ? conv_ws_kernel<T, 2, 2, 4, 2> : conv_ws_kernel<T, 2, 1, 4, 2>;
+    if (th == 8) return bn == 128 ? conv_dma_kernel<T, 4, 2, 4> : conv_dma_kernel<T, 4, 1, 4>;
+    return bn == 128 ? conv_dma_kernel<T, 2, 2, 4> : conv_dma_kernel<T, 2, 1, 4>;
 }
-static ws_fn_t pick_ws(int dtype, int ntaps, int th, int bn)
+static dma_fn_t pick_dma(int dtype, int ntaps, int th, int bn)
 {
-    return dtype == 0 ? pick_ws_t<float>(ntaps, th, bn) : pick_ws_t<__bf16>(ntaps, th, bn);
+    return dtype == 0 ? pick_dma_t<float>(ntaps, th, bn) : pick_dma_t<__bf16>(ntaps, th, bn);
 }
-static size_t ws_lds(int ntaps, int th, int bn)
+static size_t dma_lds(int th, int bn)
 {
-    if (th == 8) return bn == 128 ? WsLds<8, 128, 1>::TOTAL : WsLds<8, 64, 1>::TOTAL;
-    if (ntaps == 9) return bn == 128 ? WsLds<4, 128, 3>::TOTAL : WsLds<4, 64, 3>::TOTAL;
-    return bn == 128 ? WsLds<4, 128, 2>::TOTAL : WsLds<4, 64, 2>::TOTAL;
+    if (th == 8) return bn == 128 ? WsLds<8, 128, 3>::TOTAL : WsLds<8, 64, 3>::TOTAL;
+    return bn == 128 ? WsLds<4, 128, 3>::TOTAL : WsLds<4, 64, 3>::TOTAL;
 }
 
-bool conv_ws_supported(int kind, int bn) { return (kind == KIND_C3S1 || kind == KIND_CT4) && (bn == 128 || bn == 64); }
-
-hipError_t conv_ws_prepare()
+hipError_t conv_dma_prepare()
 {
     for (int dt = 0; dt < 2; ++dt)
         for (int ntaps = 4; ntaps <= 9; ntaps += 5)
             for (int th = 4; th <= 8; th += 4)
                 for (int bn = 64; bn <= 128; bn += 64) {
-                    hipError_t e = hipFuncSetAttribute((const void*)pick_ws(dt, ntaps, th, bn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)ws_lds(ntaps, th, bn));
+                    hipError_t e = hipFuncSetAttribute((const void*)pick_dma(dt, ntaps, th, bn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)dma_lds(th, bn));
                     if (e != hipSuccess) return e;
                 }
     return hipSuccess;
 }
 
-// Diagnostic: CCN_STAMPS=<grid>[:<ntaps>] records s_memrealtime stamps of every launch with that grid (last one wins);
-// ccn_internal_dump_stamps writes them out.  Never set in timed runs.
 static unsigned long long* g_stamps = nullptr;
 static unsigned g_stamp_grid = 0;
-extern "C" int ccn_internal_dump_stamps(const char* path)
+extern "C" int ccn_internal_dump_stamps_dma(const char* path)
 {
     if (!g_stamps || !g_stamp_grid) return 1;
     std::vector<unsigned long long> h((size_t)g_stamp_grid * 24);
     if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     FILE* f = fopen(path, "w");
     if (!f) return 3;
-    for (unsigned b = 0; b < g_stamp_grid; ++b) {
+    for (unsigned b = 0; b < g_stamp_grid; ++b)
         for (int k = 0; k < 24; ++k) fprintf(f, "%llu%c", h[(size_t)b * 24 + k], k == 23 ? '\n' : ' ');
-    }
     fclose(f);
     return 0;
 }
 
-hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s)
+hipError_t launch_conv_dma(int dtype, int bn, const ConvArgs& a, hipStream_t s)
 {
     const unsigned grid = (unsigned)(a.B * a.n_ty * a.n_tx * a.npar * a.n_nt);
     static const char* env = getenv("CCN_STAMPS");
     if (env) {
         unsigned want = (unsigned)atoi(env), want_taps = strchr(env, ':') ? (unsigned)atoi(strchr(env, ':') + 1) : 9u;
-        if (grid == want && (unsigned)a.ntaps == want_taps) {
+        if (grid == want && (unsigned)a.ntaps == want_taps && grid <= 8192) {
             if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)8192 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
-            if (grid <= 8192) {
-                g_stamp_grid = grid;
-                ConvArgs d = a; d.stamps = g_stamps;
-                hipLaunchKernelGGL(pick_ws(dtype, a.ntaps, a.th, bn), dim3(grid), dim3(512), ws_lds(a.ntaps, a.th, bn), s, d);
-                return hipGetLastError();
-            }
+            g_stamp_grid = grid;
+            ConvArgs d = a; d.stamps = g_stamps;
+            hipLaunchKernelGGL(pick_dma(dtype, a.ntaps, a.th, bn), dim3(grid), dim3(512), dma_lds(a.th, bn), s, d);
+            return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(pick_ws(dtype, a.ntaps, a.th, bn), dim3(grid), dim3(512), ws_lds(a.ntaps, a.th, bn), s, a);
+    hipLaunchKernelGGL(pick_dma(dtype, a.ntaps, a.th, bn), dim3(grid), dim3(512), dma_lds(a.th, bn), s, a);
     return hipGetLastError();
 }
 

@@ -404,6 +404,12 @@ hipError_t conv_prepare()
     return hipSuccess;
 }
 
+bool conv_dma_enabled()
+{
+    static const int on = getenv("CCN_CONV_DMA") ? atoi(getenv("CCN_CONV_DMA")) : 0;
+    return on != 0;
+}
+
 bool conv_ws_enabled()
 {
     static const int on = getenv("CCN_CONV_V1") ? 0 : 1;      // CCN_CONV_V1=1: A/B switch back to the 4-wave kernel
@@ -424,9 +430,13 @@ hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream
 {
     if (conv_ws_enabled() && conv_ws_supported(kind, bn)) {
         static const int dbg = getenv("CCN_DBG") ? atoi(getenv("CCN_DBG")) : 0;
-        if (!dbg) return launch_conv_ws(dtype, bn, a, s);
         ConvArgs d = a; d.dbg = dbg;
-        return launch_conv_ws(dtype, bn, d, s);
+        // 0 ws everywhere, 1 shared LDS-DMA ring, 2 free-running everywhere, 3 (default) free-running on 8-row tiles only:
+        // on 4-row tiles a consumer wave would issue 8 DMA pieces per 16 MFMAs and the private weight copies double the
+        // L2 traffic of the already weight-heavy 128-pixel tile
+        static const int variant = getenv("CCN_CONV_DMA") ? atoi(getenv("CCN_CONV_DMA")) : 3;
+        if (variant == 2 || (variant == 3 && a.th == 8)) return launch_conv_fr(dtype, bn, d, s);
+        return variant == 1 ? launch_conv_dma(dtype, bn, d, s) : launch_conv_ws(dtype, bn, d, s);
     }
     if (a.th != 4) return hipErrorInvalidValue;
     const conv_fn_t fn = pick(dtype, kind, bn);
