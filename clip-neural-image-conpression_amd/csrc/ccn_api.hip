@@ -54,6 +54,7 @@ struct ConvW {
     int kind = KIND_C3S1;
     int Cin = 0, Cout = 0, Cin_pad = 0, Cout_pad = 0, BN = 0, ntaps_w = 0;
     void* w = nullptr;
+    void* wfrag = nullptr;      // MFMA-fragment-ordered copy for the persistent 3x3 kernel (Cout_pad % 128 == 0), else null
     float* bias = nullptr;
 };
 struct NormW { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
@@ -72,6 +73,7 @@ struct TensorRef {
     int C = 0, H = 0, W = 0;
     float2* part = nullptr;      // GroupNorm partial sums written by the producer
     int n_sp = 0, n_nt = 0, bn = 0;
+    bool pr = false;             // partial sums laid out per consumer wave (persistent kernel)
     std::shared_ptr<ConvArgs> prod;   // launch arguments of the producing conv (patched when its GroupNorm finalize is fused in)
 };
 
@@ -268,6 +270,29 @@ int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2
     const int I = cw.Cin;
     int rc = pack_and_upload(h, cw, 9, [&](int t, int o, int i) { return i < I ? w[((size_t)o * I + i) * 9 + t] : 0.f; });
     if (rc) return rc;
+    if (cw.kind == KIND_C3S1 && cw.BN == 128) {
+        // fragment order for ccn_conv_pr.hip: [chunk][Cout_pad/32][tap][kk][lane = h*32 + r][EPC]; lane (r, h) of column n32
+        // holds output channel n32*32 + r, input channels chunk*cke + (2*kk + h)*EPC + e -- one wave load = 1 KiB contiguous
+        const int epc = cke / 8, nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32, O = cw.Cout;
+        const size_t n = (size_t)nch * n32 * 9 * 4 * 64 * epc;
+        std::vector<float> tmp(n, 0.f);
+        size_t p = 0;
+        for (int c = 0; c < nch; ++c)
+            for (int nn = 0; nn < n32; ++nn)
+                for (int t = 0; t < 9; ++t)
+                    for (int kk = 0; kk < 4; ++kk)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < epc; ++e, ++p) {
+                                const int o = nn * 32 + (ln & 31), i = c * cke + (2 * kk + (ln >> 5)) * epc + e;
+                                tmp[p] = (o < O && i < I) ? w[((size_t)o * I + i) * 9 + t] : 0.f;
+                            }
+        if (h->cfg.dtype == CCN_DTYPE_BF16) {
+            std::vector<uint16_t> b16(n);
+            for (size_t q = 0; q < n; ++q) b16[q] = f2bf_host(tmp[q]);
+            rc = upload(h, b16.data(), n * 2, &cw.wfrag);
+        } else rc = upload(h, tmp.data(), n * 4, &cw.wfrag);
+        if (rc) return rc;
+    }
     return upload_f32(h, name + ".bias", &cw.bias);
 }
 int pack_convT(ccn_handle_s* h, ConvW& cw, const std::string& name)     // ConvTranspose2d weight (I, O, 4, 4)
@@ -351,7 +376,7 @@ struct PlanBuilder {
         const ConvGeom g = conv_geom(cw, B, in.H, in.W);
         std::shared_ptr<ConvArgs> ap(new ConvArgs());
         ConvArgs& a = *ap;
-        a.in = in.p; a.w = cw.w; a.bias = cw.bias; a.out = out.p;
+        a.in = in.p; a.w = cw.w; a.wfrag = cw.wfrag; a.bias = cw.bias; a.out = out.p;
         a.gn_ab = gn_ab; a.film = nullptr; a.res = res ? res->p : nullptr;
         a.B = B; a.Hin = in.H; a.Win = in.W; a.Cin = cw.Cin; a.Cin_pad = cw.Cin_pad;
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = cw.Cout; a.Cout_pad = cw.Cout_pad;
@@ -362,11 +387,18 @@ struct PlanBuilder {
         a.silu = 1;
         a.G = groups_for(cw.Cout); a.cpg = cw.Cout / a.G;
         a.nslot = g.n_ty * g.n_tx * g.npar * g.n_nt;
+        // the persistent kernel publishes one partial per producer wave (4 per tile)
+        const bool pr = cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 &&
+                        (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
+        if (!pr) a.wfrag = nullptr;
+        a.use_pr = pr ? 1 : 0;
+        if (pr) a.nslot *= 4;
         a.film_bstride = film_stride;
         fill_taps(a, cw.kind);
         if (want_part) {
             out.part = (float2*)bump.take((size_t)B * a.G * a.nslot * sizeof(float2));
             out.n_sp = g.n_ty * g.n_tx * g.npar; out.n_nt = g.n_nt; out.bn = cw.BN;
+            if (pr) { out.n_sp *= 4; out.pr = true; }       // one slot per producer wave
         }
         a.part = out.part;
         a.bn = cw.BN;
@@ -404,7 +436,7 @@ struct PlanBuilder {
         // measured slower than the 5 us finalize launch it removes (every workgroup drains its stores and pays an atomic
         // round trip before exiting): 50.4 vs 52.1 img/s at C2, so opt-in only
         static const bool fuse = getenv("CCN_FUSED_FINALIZE") != nullptr;
-        if (fuse && t.prod && plan->counters && plan->n_counters < kMaxNorms) {
+        if (fuse && t.prod && !t.pr && plan->counters && plan->n_counters < kMaxNorms) {
             // the producing conv's last workgroup per sample does the finalize (no launch, no kernel boundary)
             ConvArgs& pa = *t.prod;
             pa.fin_counter = plan->counters + (size_t)plan->n_counters * B;

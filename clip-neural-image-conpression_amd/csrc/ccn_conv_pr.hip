@@ -1,0 +1,513 @@
+// Persistent implicit-GEMM 3x3 stride-1 convolution with the weight operand in registers (bf16 throughput mode).
+//
+// What the free-running kernel (ccn_conv_fr.hip) still pays, measured per 8x32-pixel tile of a C=128 layer: a ~6-8 us
+// serial prologue (cold fetch of the first input chunk), a ~4.7 us serial epilogue, and a main loop that runs at ~55 %
+// of the MFMA rate because the LDS port is saturated: 96 B/clk of fragment reads plus 32 B/clk of weight LDS-DMA
+// writes against a 128 B/clk port.  This kernel removes all three:
+//   * weights never touch LDS: the host packs them in MFMA fragment order (one 1 KiB wave load = one 32-channel x
+//     16-byte fragment column) and every consumer wave streams its own fragments from L2 straight into a ring of D
+//     steps of registers, D-1 steps (~1300 clk) ahead of use.  LDS traffic drops to the input fragments (64 B/clk);
+//   * the input chunk buffers are double buffered in the space the weight rings used: a chunk boundary is ONE barrier
+//     and the producers write the next chunk while the consumers compute;
+//   * a workgroup is persistent: it walks tiles vb, vb+grid, ...  The producer waves run one chunk ahead ACROSS tile
+//     boundaries and the weight ring keeps streaming, so a tile has no prologue;
+//   * the consumers have no epilogue either: at the end of a tile they round the accumulators to bf16 into a staging
+//     tile in LDS (32 ds_write_b64 per wave; the MFMA operands are swapped so a lane holds 4 consecutive channels of
+//     one pixel) and go straight on to the next tile.  The PRODUCER waves -- idle most of a chunk -- finish the
+//     previous tile during the next tile's first chunk: staging -> bias / FiLM / residual (rows prefetched into their
+//     registers one chunk earlier) -> 16-byte NHWC stores, and the next GroupNorm's partial sums (one slot per
+//     producer wave).
+// Tile: 8 rows x 32 pixels x 128 output channels, 4 consumer waves (2x2, 4x2 fragments of 32x32) + 4 producer waves.
+// Rounding: the conv accumulator is rounded to bf16 once before the affine/residual and the sum once more on store
+// (the other kernels round once); both are within the bf16 mode's error budget (tests/test_gpu_parity.py bounds).
+#include "ccn_device.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace ccn {
+
+namespace {
+
+struct PrLds {
+    static constexpr int HROWS = 10, HPITCH = 34;
+    static constexpr int A_BYTES = HROWS * HPITCH * 128;       // one Cin chunk of the halo tile (43520)
+    static constexpr int AU = HROWS * HPITCH;                   // halo pixels
+    static constexpr int SP = 272;                              // staging pitch in bytes: 128 bf16 channels + 16
+    static constexpr int STG_BYTES = 256 * SP;                  // 256 pixels
+    static constexpr int CHS_BYTES = 4 * 128 * 2 * 4;           // per producer wave: per-channel (sum, sum of squares)
+    static constexpr int TOTAL = 2 * A_BYTES + STG_BYTES + CHS_BYTES;
+};
+static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
+
+}  // namespace
+
+// RES: epilogue adds the residual tensor and ignores FiLM (ResBlock conv2); !RES: bias / FiLM only (conv1).  Separate
+// instantiations keep the producers' register footprint down: they hold either residual rows or FiLM vectors, never both.
+template <int NTAPS, int D, bool RES>
+__global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
+{
+    typedef __bf16 T;
+    constexpr int MF = 4, NF = 2;
+    constexpr int TH = 8, BN = 128;
+    constexpr int EPC = 8, CKE = 64;
+    constexpr int NSTEP = NTAPS * 4;                           // step = tap * 4 + kk (one 16-byte K slice per lane half)
+    static_assert(NSTEP % D == 0, "the register ring must wrap at the chunk boundary");
+    using L = PrLds;
+    constexpr int HPITCH = L::HPITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const stg = smem + 2 * L::A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware block -> tile-stream mapping: consecutive hardware block ids go round-robin over the 8 XCDs, so give
+    // XCD x the contiguous virtual ids [x*grid/8, (x+1)*grid/8): neighbouring tiles (shared halos, the two N tiles of one
+    // pixel tile) then meet in the same L2.
+    const int grid = (int)gridDim.x;
+    const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int ntiles = grid_tiles;
+    const int my_tiles = (ntiles - vb + grid - 1) / grid;      // >= 1 (grid <= ntiles)
+    const int ktotal = my_tiles * a.nchunk;
+
+    const unsigned char* const inb = (const unsigned char*)a.in;
+    const bool gn = a.gn_ab != nullptr && !(a.dbg & 32);     // CCN_DBG=32: skip the transform (timing experiments only)
+    constexpr unsigned OOB = 0x7FFFFFF0u;
+    const unsigned in_bytes = (unsigned)((size_t)a.B * a.Hin * a.Win * a.Cin * sizeof(T));
+    auto raw_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a.stamps && lane == 0 && (wave == 0 || wave == 4))
+            a.stamps[((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+    // diagnostics (CCN_STAMPS): shader-clock cycles spent waiting at barriers / in phases, per role
+    unsigned long long t_bar = 0, t_a = 0, t_b = 0, t_w = 0, t_r = 0;
+    const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+    auto timed_barrier = [&]() __attribute__((always_inline)) {
+        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); t_bar += __builtin_amdgcn_s_memtime() - t0; }
+        else raw_barrier();
+    };
+    auto stamp_cycles = [&]() __attribute__((always_inline)) {
+        if (a.stamps && lane == 0 && (wave == 0 || wave == 4)) {
+            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8;
+            st[3] = t_bar; st[4] = __builtin_amdgcn_s_memtime() - t_begin; st[5] = t_a; st[6] = t_b; st[7] = t_w; st[1] = t_r;
+        }
+    };
+    stamp(0);
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers (4 waves): input chunks + tile epilogues
+        // The VALU is the scarce resource here (GroupNorm + SiLU costs ~45 VALU per 16 bytes, a quarter of them
+        // transcendental, next to a consumer wave that owns the SIMD's issue priority), so the per-item address math is
+        // reduced to one add: item i of a thread is halo row i at a fixed column, offsets are base + i * row stride, row
+        // validity is wave-uniform, and everything is branch-free (out-of-range offsets make loads return zero).
+        const int ptid = tid - 256, pw = wave - 4;
+        const int ck = ptid & 7, pcol = ptid >> 3;                // 16-byte channel slice, halo column 0..31
+        // the two halo columns 32, 33 (10 rows x 8 slices = 160 units) go to threads 0..159 as an eleventh item
+        const int xrow = pcol >> 1, xcol = 32 + (pcol & 1);
+        const bool xthr = ptid < 160;
+        constexpr int AIT = 11;
+        u32x4 areg[AIT];
+        GnCoef<T> gk;
+        unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
+        bool colv = false, xv = false;           // this thread's column / extra item inside the image
+        int rq_ti = 0, rq_c = 0;
+        // A request is split in two: prep() at the START of an iteration decodes the tile and fetches the GroupNorm
+        // coefficients of the chunk into a second register set; issue() after dump() sends the 11 input loads and adopts the
+        // coefficients.  (Fetched inside issue(), the coefficient loads made the wave wait a full L2 latency right there.)
+        GnCoef<T> gkn;
+        int q_b = 0, q_iy0 = 0, q_ix0 = 0, q_c = 0;
+        bool q_tv = false;
+        auto prep = [&]() __attribute__((always_inline)) {
+            const int tile = vb + rq_ti * grid;
+            q_tv = tile < ntiles;
+            const int sp = (q_tv ? tile : vb) / a.n_nt;
+            const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
+            q_b = sp / (a.n_tx * a.n_ty);
+            q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = rq_c;
+            const int cb = q_c * CKE + ck * EPC;
+            const bool cv = q_tv && cb < a.Cin;
+            gkn.load(a.gn_ab + (size_t)q_b * a.Cin + (cv ? cb : 0), gn && cv);
+            if (++rq_c == a.nchunk) { rq_c = 0; ++rq_ti; }
+        };
+        auto issue = [&]() __attribute__((always_inline)) {
+            const int b = q_b, iy0 = q_iy0, ix0 = q_ix0;
+            const int cb = q_c * CKE + ck * EPC;
+            const bool cv = q_tv && cb < a.Cin;
+            gk = gkn;
+            const unsigned coff = (unsigned)((size_t)(cv ? q_c : 0) * CKE * sizeof(T));
+            const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + coff), 0, in_bytes - coff, 0x00020000);
+            const int rs = a.Win * a.Cin * (int)sizeof(T);                        // row stride in bytes
+            const int ix = ix0 + pcol;
+            colv = cv && ix >= 0 && ix < a.Win;
+            // branch-free validity: OR an out-of-range constant into the offset (an invalid row or column may have produced
+            // any value, negative included -- all of them stay past num_records once the mask is ORed in)
+            const unsigned cmask = colv ? 0u : OOB;
+            const int base = ((b * a.Hin + iy0) * a.Win + ix) * a.Cin * (int)sizeof(T) + ck * 16;
+            rowm = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const bool rv = iy0 + i >= 0 && iy0 + i < a.Hin;                  // wave-uniform
+                const unsigned rmask = rv ? 0u : OOB;
+                rowm |= rv ? (1u << i) : 0u;
+                areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask | rmask, 0, 0);
+            }
+            {
+                const int iy = iy0 + xrow, ixx = ix0 + xcol;
+                xv = xthr && cv && iy >= 0 && iy < a.Hin && ixx < a.Win;
+                const int off = ((b * a.Hin + iy) * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
+                areg[10] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
+            }
+        };
+        auto request = [&]() __attribute__((always_inline)) { prep(); issue(); };
+        auto dump = [&](int buf) __attribute__((always_inline)) {
+            unsigned char* const As = smem + buf * L::A_BYTES;
+            int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
+            const int swz0 = pc >> 1;
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                u32x4 v = areg[i];
+                const bool ok = i < 10 ? (((rowm >> i) & 1u) && colv) : xv;
+                if (gn) {
+                    const u32x4 tr = gk.template apply<true>(v);
+                    v = u32x4{ok ? tr[0] : 0u, ok ? tr[1] : 0u, ok ? tr[2] : 0u, ok ? tr[3] : 0u};   // padding stays zero
+                }
+                const int px = i < 10 ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
+                const int sw = i < 10 ? (swz0 + i) : (px >> 1);              // (px >> 1) & 7 == (i*17 + (pcol>>1)) & 7
+                if (i < 10 || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
+                if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
+            }
+        };
+
+        // ---- epilogue: thread -> fixed channel octet o16 of the tile's 128, pixels pr + 16*it (it < 16) of its 256:
+        // row it>>1, column pr + 16*(it&1); residual rows, bias and FiLM are fetched during the tile's last chunk
+        const int o16 = ptid & 15, pr = ptid >> 4;
+        unsigned char* const outb = (unsigned char*)a.out;
+        const unsigned char* const resb = (const unsigned char*)a.res;
+        const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
+        const auto osrd = __builtin_amdgcn_make_buffer_rsrc((void*)outb, 0, out_bytes, 0x00020000);
+        const auto rsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(resb ? resb : outb), 0, out_bytes, 0x00020000);
+        float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
+        u32x4 rr[RES ? 2 : 1][4];                // residual rows, batches of 4 items (two tile rows), two batches in flight
+        f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
+        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0;
+        unsigned e_base = 0;
+        int e_rows = 0;                          // wave-uniform: valid rows of the tile
+        unsigned e_m0 = OOB, e_m1 = OOB;         // 0 when this thread's first / second column (and its octet) is inside the tensor
+        // byte offset of item it (row it>>1, column pr + 16*(it&1)); masked-out items land past num_records.  Callers pass a
+        // laundered copy of e_base: otherwise the 16 offsets are computed once per tile and kept live across dump() and the barrier
+        auto item_off = [&](unsigned eb, int it) __attribute__((always_inline)) -> unsigned {
+            const unsigned rmask = (it >> 1) < e_rows ? 0u : OOB;                 // wave-uniform
+            return (eb + (unsigned)(it >> 1) * (unsigned)(a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.Cout * (int)sizeof(T)))
+                   | ((it & 1) ? e_m1 : e_m0) | rmask;
+        };
+        // during the tile's last chunk: decode the tile
+        auto epi_setup = [&](int tile) __attribute__((always_inline)) {
+            e_nt = tile % a.n_nt;
+            const int sp = tile / a.n_nt;
+            e_tx = sp % a.n_tx; e_ty = (sp / a.n_tx) % a.n_ty; e_b = sp / (a.n_tx * a.n_ty);
+            const int nb = e_nt * BN + o16 * 8;
+            const bool nvalid = nb < a.Cout;
+            e_base = (unsigned)(((e_b * a.Hout + e_ty * TH) * a.Wout + e_tx * 32 + pr) * a.Cout + nb) * (unsigned)sizeof(T);
+            e_rows = a.MH - e_ty * TH;
+            e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
+            e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
+        };
+        auto res_batch = [&](int q, u32x4* dst) __attribute__((always_inline)) {
+            if constexpr (RES) {
+                unsigned eb = e_base; asm volatile("" : "+v"(eb));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, item_off(eb, q * 4 + i), 0, 0);
+            }
+        };
+        // start of the epilogue iteration: bias / FiLM (raw: folding them here would wait for the loads) and the first two
+        // residual batches; all of it flies during request()
+        auto epi_request = [&]() __attribute__((always_inline)) {
+            const int nb = e_nt * BN + o16 * 8;
+            const int nbs = nb < a.Cout ? nb : 0;
+            fb[0] = *(const f32x4*)(a.bias + nbs); fb[1] = *(const f32x4*)(a.bias + nbs + 4);
+            if constexpr (!RES) {
+                if (a.film) {
+                    const float* fp = a.film + (size_t)e_b * a.film_bstride;
+                    fs[0] = *(const f32x4*)(fp + nbs); fs[1] = *(const f32x4*)(fp + nbs + 4);
+                    ft[0] = *(const f32x4*)(fp + a.Cout + nbs); ft[1] = *(const f32x4*)(fp + a.Cout + nbs + 4);
+                }
+            }
+            res_batch(0, rr[0]);
+            if constexpr (RES) res_batch(1, rr[1]);
+        };
+        // the staging tile of the tile described by e_* is complete (the consumers wrote it before the last barrier)
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            // scalar fp32 math only (packed-fp32 ops starve next to the consumers' MFMA stream, see GnCoef), and the running
+            // sums pinned per item: left alone the compiler sums ACROSS the 16 unrolled items at the end and keeps all 128
+            // output values alive until then
+            float f1[RES ? 1 : 8], f2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f2[e] = fb[e >> 2][e & 3];
+                if constexpr (!RES) {
+                    f1[e] = 1.f;
+                    if (a.film) { f1[e] = 1.0f + fs[e >> 2][e & 3]; f2[e] = fmaf(f2[e], f1[e], ft[e >> 2][e & 3]); }
+                }
+            }
+            float s1[8], s2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned eb = e_base; asm volatile("" : "+v"(eb));
+                int sbase = pr * L::SP + o16 * 16; asm volatile("" : "+v"(sbase));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int it = q * 4 + i;
+                    const unsigned off = item_off(eb, it);
+                    const u32x4 sv = *(const u32x4*)(stg + sbase + ((it >> 1) * 32 + (it & 1) * 16) * L::SP);
+                    const float mk = off < OOB ? 1.0f : 0.0f;             // masked items contribute nothing to the statistics
+                    float x[8];
+                    Vec16<T>::unpack(sv, x);
+                    if constexpr (RES) {
+                        float rv[8];
+                        Vec16<T>::unpack(rr[q & 1][i], rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = (x[e] + f2[e]) + rv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], f1[e], f2[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd, off, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float u = x[e] * mk; s1[e] += u; s2[e] = fmaf(u, x[e], s2[e]); }
+                    asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
+                    asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (RES) { if (q + 2 < 4) res_batch(q + 2, rr[q & 1]); }   // refill the buffer just consumed, one batch ahead
+            }
+            if (a.part) {
+#pragma unroll
+                for (int s = 16; s < 64; s <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], s); s2[e] += __shfl_xor(s2[e], s); }
+                if (lane < 16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { chs[(lane * 8 + e) * 2] = s1[e]; chs[(lane * 8 + e) * 2 + 1] = s2[e]; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS is in order per wave
+                const int n0 = e_nt * BN;
+                if (n0 < a.Cout) {
+                    const int nend = min(n0 + BN, a.Cout);
+                    const int g = n0 / a.cpg + lane;
+                    if (g <= (nend - 1) / a.cpg) {
+                        const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
+                        float t1 = 0.f, t2 = 0.f;
+                        for (int c = clo; c < chi; ++c) { t1 += chs[(c - n0) * 2]; t2 += chs[(c - n0) * 2 + 1]; }
+                        const int slot = ((e_ty * a.n_tx + e_tx) * 4 + pw) * a.n_nt + e_nt;
+                        part_store(a.part + (size_t)(e_b * a.G + g) * a.nslot + slot, t1, t2);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // sums consumed before the next epilogue rewrites them
+            }
+        };
+
+        request();
+        dump(0);
+        request();
+        raw_barrier();                                             // chunk 0 visible
+        stamp(1);
+        int c = 0, ti = 0;
+        for (int k = 0; k < ktotal; ++k) {
+            unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+            if (a.stamps) {                                        // diagnostic: separate the wait for the chunk registers from the work
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_w += t1 - t0; t0 = t1;
+            }
+            if (k + 1 < ktotal) { prep(); dump((k + 1) & 1); }
+            if (a.stamps) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
+            const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
+            if (epi) epi_request();
+            if (k + 1 < ktotal) issue();
+            if (c == a.nchunk - 1) epi_setup(vb + ti * grid);      // this tile finishes in this iteration
+            if (a.stamps) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
+            if (epi) epilogue();
+            if (a.stamps) t_b += __builtin_amdgcn_s_memtime() - t0;
+            timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
+            if (++c == a.nchunk) { c = 0; ++ti; }
+        }
+        epi_request();
+        epilogue();                                                // last tile
+        stamp(2); stamp_cycles();
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers (4 waves)
+    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[MF][NF];
+    auto rbase = [&](int row) __attribute__((always_inline)) { return row * 128 + ((((row >> 1) & 6)) << 4) + (((h ^ (row >> 1)) & 1) << 4); };
+    int prow[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) prow[i] = ((wm * MF + i) + 1) * HPITCH + r + 1;
+    // weight fragments: [chunk][Cout_pad/32][tap][kk][lane] x 16 B (host-packed); this wave owns columns nt*4 + wn*2 + {0,1}
+    const int n32 = a.Cout_pad / 32;
+    constexpr unsigned COLB = NSTEP * 1024;                        // bytes of one 32-channel column of one chunk
+    const unsigned wtotal = (unsigned)((size_t)a.nchunk * n32 * COLB);
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
+        const int nt = tile % a.n_nt;
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(chunk * n32 + nt * 4 + wn * NF) * COLB));
+    };
+    u32x4 bq[D][NF];
+    {
+        const unsigned wb = wbase_of(vb, 0);
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+            for (int jn = 0; jn < NF; ++jn) bq[s][jn] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, wb + s * 1024 + jn * COLB, 0);
+    }
+    // staging address of this lane: pixel (wm*4 + i)*32 + r, channels wn*64 + j*32 + g*8 + 4*h .. +3
+    const int stg_lane = (wm * 4 * 32 + r) * L::SP + (wn * 64 + 4 * h) * 2;
+
+    raw_barrier();                                                 // chunk 0 visible
+    stamp(1);
+    int k = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int tile = vb + ti * grid;
+        const int tile_next = tile + grid < ntiles ? tile + grid : tile;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+        for (int chunk = 0; chunk < a.nchunk; ++chunk, ++k) {
+            const unsigned wb_cur = wbase_of(tile, chunk);
+            const unsigned wb_nxt = chunk + 1 < a.nchunk ? wbase_of(tile, chunk + 1) : wbase_of(tile_next, 0);
+            const int bufoff = (k & 1) * L::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop
+            u32x4 av[2][MF];
+            int abase[MF];
+            auto frag = [&](int j, u32x4* av_) __attribute__((always_inline)) {
+                const int tt = j >> 2, kk = j & 3;
+                if (kk == 0) {
+                    const int toff = NTAPS == 9 ? (tt / 3 - 1) * HPITCH + (tt % 3 - 1) : 0;
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toff);
+                }
+#pragma unroll
+                for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
+            };
+            if (!(a.dbg & 64)) {                                   // CCN_DBG=64: consumers idle (timing experiments only)
+            frag(0, av[0]);
+#pragma unroll
+            for (int j = 0; j < NSTEP; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    // refill the ring slot step j-1 just released with the fragments of step j+D-1 (wraps into the next chunk / tile)
+                    const int p = j + D - 1;
+                    const unsigned off = p < NSTEP ? wb_cur + (unsigned)p * 1024u : wb_nxt + (unsigned)(p - NSTEP) * 1024u;
+#pragma unroll
+                    for (int jn = 0; jn < NF; ++jn)
+                        bq[p % D][jn] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off + jn * COLB, 0);
+                }
+                if (j + 1 < NSTEP) frag(j + 1, av[(j + 1) & 1]);
+                // operands swapped (weights as the MFMA A operand): a lane's accumulator registers run over output
+                // channels ((q&3) + 8*(q>>2) + 4*h) of pixel r, i.e. 4 consecutive channels per register quad
+#pragma unroll
+                for (int jn = 0; jn < NF; ++jn)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) mfma16<T>(acc[i][jn], bq[j % D][jn], av[j & 1][i]);
+                // one MFMA, then (in its shadow) one weight load, one LDS fragment read and a little address math of the next step
+#pragma unroll
+                for (int m = 0; m < MF * NF; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m < NF) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            }
+            if (chunk + 1 == a.nchunk) {
+                // hand the tile to the producers: bf16 staging, 8 bytes (4 channels) per store
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& c = acc[i][j];
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 pk = {pack_bf2(c[g * 4], c[g * 4 + 1]), pack_bf2(c[g * 4 + 2], c[g * 4 + 3])};
+                            *(u32x2*)(stg + stg_lane + i * 32 * L::SP + (j * 32 + g * 8) * 2) = pk;
+                        }
+            }
+            timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    stamp(2); stamp_cycles();
+}
+
+// ---- dispatch -------------------------------------------------------------------------------------------------
+typedef void (*pr_fn_t)(const ConvArgs, int);
+static pr_fn_t pick_pr(bool res) { return res ? (pr_fn_t)conv_pr_kernel<9, 6, true> : (pr_fn_t)conv_pr_kernel<9, 6, false>; }
+
+bool conv_pr_supported(int kind, int bn, int th) { return kind == KIND_C3S1 && bn == 128 && th == 8; }
+
+static int g_cus = 0;
+hipError_t conv_pr_prepare()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)pick_pr(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)pick_pr(true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    g_cus = prop.multiProcessorCount;
+    return hipSuccess;
+}
+
+static unsigned long long* g_stamps = nullptr;
+static unsigned g_stamp_grid = 0;
+extern "C" int ccn_internal_dump_stamps_pr(const char* path)
+{
+    if (!g_stamps || !g_stamp_grid) return 1;
+    std::vector<unsigned long long> hbuf((size_t)g_stamp_grid * 16);
+    if (hipMemcpy(hbuf.data(), g_stamps, hbuf.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    FILE* f = fopen(path, "w");
+    if (!f) return 3;
+    for (unsigned b = 0; b < g_stamp_grid; ++b)
+        for (int k = 0; k < 16; ++k) fprintf(f, "%llu%c", hbuf[(size_t)b * 16 + k], k == 15 ? '\n' : ' ');
+    fclose(f);
+    return 0;
+}
+
+hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
+{
+    if (dtype != 1 || !a.wfrag || a.npar != 1 || a.ntaps != 9 || a.th != 8 || a.OS != 1 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
+    const int ntiles = a.B * a.n_ty * a.n_tx * a.n_nt;
+    static const int cap = getenv("CCN_PR_GRID") ? atoi(getenv("CCN_PR_GRID")) : 0;
+    int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);
+    if (grid > ntiles) grid = ntiles;
+    ConvArgs d = a;
+    static const char* env = getenv("CCN_STAMPS");
+    if (env && (unsigned)atoi(env) == (unsigned)ntiles) {
+        if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
+        g_stamp_grid = (unsigned)grid;
+        d.stamps = g_stamps;
+    } else d.stamps = nullptr;
+    hipLaunchKernelGGL(pick_pr(a.res != nullptr), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
+    return hipGetLastError();
+}
+
+}  // namespace ccn

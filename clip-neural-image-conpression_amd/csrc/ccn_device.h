@@ -70,9 +70,10 @@ template <> struct GnCoef<float> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = 1.f; c[e] = 0.f; }
         if (valid) {
+            // table layout per channel pair: {scale(2p), scale(2p+1), shift(2p), shift(2p+1)}
             const f32x4 v0 = *(const f32x4*)ab, v1 = *(const f32x4*)(ab + 2);
-            a[0] = v0[0]; c[0] = v0[1]; a[1] = v0[2]; c[1] = v0[3];
-            a[2] = v1[0]; c[2] = v1[1]; a[3] = v1[2]; c[3] = v1[3];
+            a[0] = v0[0]; a[1] = v0[1]; c[0] = v0[2]; c[1] = v0[3];
+            a[2] = v1[0]; a[3] = v1[1]; c[2] = v1[2]; c[3] = v1[3];
         }
     }
     template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
@@ -87,36 +88,36 @@ template <> struct GnCoef<float> {
         return Vec16<float>::pack(v);
     }
 };
+// NO packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) here or anywhere in a producer wave: next to a
+// wave that streams MFMAs they are starved outright -- tools/ubench/dump_vs_mfma.hip: this transform goes from 150 to
+// >2300 cycles per 16 bytes as soon as one v_pk_mul_f32 is in it, while v_fma_f32 / v_mul_f32 / v_exp_f32 lose ~25 %.
+// The file is built with -fno-slp-vectorize so that scalar code stays scalar.
 template <> struct GnCoef<__bf16> {
-    f32x2 a[4], c[4], an[4], cn[4];
+    float a[8], c[8];
     __device__ __forceinline__ void load(const float2* ab, bool valid) {
-        const float nl2e = -1.4426950408889634f;
         f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f32x4{1.f, 0.f, 1.f, 0.f};
+        for (int e = 0; e < 4; ++e) v[e] = f32x4{1.f, 1.f, 0.f, 0.f};
         if (valid) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = *(const f32x4*)(ab + 2 * e);        // 4 x 16 B, all in flight together
         }
+        // pair-interleaved table {scale, scale, shift, shift}: pure renaming, nothing here waits for the loads
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = f32x2{v[e][0], v[e][2]}; c[e] = f32x2{v[e][1], v[e][3]};
-            an[e] = a[e] * nl2e; cn[e] = c[e] * nl2e;
-        }
+        for (int e = 0; e < 4; ++e) { a[2 * e] = v[e][0]; a[2 * e + 1] = v[e][1]; c[2 * e] = v[e][2]; c[2 * e + 1] = v[e][3]; }
     }
     template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
+        const float nl2e = -1.4426950408889634f;
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned u = raw[e];
-            const f32x2 x = {bf_lo(u), bf_hi(u)};
-            f32x2 y = __builtin_elementwise_fma(x, a[e], c[e]);
+            float y0 = fmaf(bf_lo(u), a[2 * e], c[2 * e]), y1 = fmaf(bf_hi(u), a[2 * e + 1], c[2 * e + 1]);
             if (SILU) {
-                const f32x2 t = __builtin_elementwise_fma(x, an[e], cn[e]);          // -y * log2(e)
-                const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
-                y = y * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                const float d0 = __builtin_amdgcn_exp2f(y0 * nl2e) + 1.0f, d1 = __builtin_amdgcn_exp2f(y1 * nl2e) + 1.0f;
+                y0 *= __builtin_amdgcn_rcpf(d0); y1 *= __builtin_amdgcn_rcpf(d1);
             }
-            o[e] = pack_bf2(y[0], y[1]);
+            o[e] = pack_bf2(y0, y1);
         }
         return o;
     }
@@ -160,7 +161,9 @@ __device__ __forceinline__ void gn_reduce_group(const float2* part, int b, int g
     const double rstd = 1.0 / sqrt(var + (double)eps);
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
         const double sc = (double)gamma[c] * rstd;
-        ab[(size_t)b * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+        // pair-interleaved: channels (2p, 2p+1) -> {scale, scale, shift, shift} (see GnCoef::load)
+        float* const row = (float*)(ab + (size_t)b * C) + 4 * (c >> 1) + (c & 1);
+        row[0] = (float)sc; row[2] = (float)((double)beta[c] - mean * sc);
     }
 }
 

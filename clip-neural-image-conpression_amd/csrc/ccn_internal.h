@@ -18,9 +18,11 @@ enum ConvKind { KIND_C3S1 = 0, KIND_C3S2 = 1, KIND_CT4 = 2, KIND_STEM = 3, KIND_
 struct ConvArgs {
     const void* in;         // NHWC T [B][Hin][Win][Cin]   (stem: NCHW fp32 [B][Cin][Hin][Win])
     const void* w;          // packed [tap][Cout_pad][Cin_pad] T
+    const void* wfrag;      // 3x3 s1 layers with Cout_pad % 128 == 0: the same weights in MFMA fragment order
+                            // [Cin chunk][Cout_pad/32][tap][kk 0..3][lane 0..63] x 16 B (ccn_conv_pr.hip), else null
     const float* bias;      // [Cout]
     void* out;              // NHWC T [B][Hout][Wout][Cout] (head: unused)
-    const float2* gn_ab;    // prologue GroupNorm as per-(b,channel) (scale, shift), or null
+    const float2* gn_ab;    // prologue GroupNorm: per sample C float2 slots, pair-interleaved {scale(2p), scale(2p+1), shift(2p), shift(2p+1)}, or null
     const float* film;      // epilogue FiLM for this step: [B][film_bstride], s at [n], shift at [Cout+n]; or null
     const void* res;        // epilogue residual / skip, NHWC T like out; or null
     float2* part;           // epilogue GroupNorm partial sums [B][G][nslot] (sum, sum of squares); or null
@@ -42,6 +44,7 @@ struct ConvArgs {
     unsigned long long* stamps;   // in-kernel s_memtime stamps [block][8] (diagnostic builds of the launch only), or null
     int dbg;                // ablation switches for profiling (CCN_DBG env): 1 no A staging in loop, 2 no B staging, 4 no MFMA, 8 no epilogue
     int th;                 // tile rows of 32 pixels per workgroup (4; 8 for the large warp-specialised tiles)
+    int use_pr;             // decided at plan time: this launch runs the persistent kernel (its GroupNorm slot layout differs)
     int n_ty, n_tx, n_nt, nchunk, ntaps;
     int silu;               // SiLU after the prologue GroupNorm
     int cpg, G, nslot;      // output GroupNorm geometry
@@ -71,6 +74,13 @@ hipError_t launch_conv_dma(int dtype, int bn, const ConvArgs& a, hipStream_t s);
 // free-running variant (ccn_conv_fr.hip): private per-wave weight rings by LDS-DMA, no barrier inside a Cin chunk
 hipError_t conv_fr_prepare();
 hipError_t launch_conv_fr(int dtype, int bn, const ConvArgs& a, hipStream_t s);
+
+// persistent variant (ccn_conv_pr.hip): weights streamed from L2 into registers, double-buffered input chunks, per-wave
+// epilogue; GroupNorm partial slots are per consumer wave: n_sp*2 spatial x n_nt*2 channel columns of 64
+bool conv_pr_supported(int kind, int bn, int th);
+bool conv_pr_selected(int dtype, int kind, int bn, int th);   // supported and chosen by the variant switch
+hipError_t conv_pr_prepare();
+hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s);
 
 // GroupNorm-apply + SiLU as its own pass (NHWC T -> NHWC T).  Used in front of convs whose input is re-staged by
 // several N tiles (Cout >= 256): the transform then runs once per element instead of once per (N tile x halo).

@@ -286,3 +286,33 @@ def test_c2_batch8_bf16_is_finite_and_close_to_batch1(synth, c2_sd):
     full = sampler.sample(net, z, (8, 3, 256, 256), steps=3, x_T=xT)
     one = sampler.sample(net, z[5:6], (1, 3, 256, 256), steps=3, x_T=xT[5:6])
     assert torch.isfinite(full).all() and maxerr(one[0], full[5]) < 5e-2, maxerr(one[0], full[5])
+
+
+def test_persistent_kernel_on_ragged_tiles_matches_free_running_and_fp32(synth, c2_sd):
+    """The persistent register-weight kernel (bf16, 8-row tiles of 32 pixels, csrc/ccn_conv_pr.hip) on a batch whose
+    feature maps end in PARTIAL column tiles (200 x 168 -> 25 x 5.25 tiles) and partial row tiles (100 x 84 at the next level
+    -> 12.5 x 2.6 tiles; sizes must be multiples of 8 for the three stride-2 levels), against
+    (a) the free-running kernel on the same bf16 data path and (b) the fp32 parity mode.  Bounds: the two bf16 kernels
+    differ only by one extra bf16 rounding of the conv accumulator and the summation order of the GroupNorm partials
+    (measured 2.1e-3 max-abs at 256 px); bf16 vs fp32 is the documented 2e-2 forward bound."""
+    lib = _native.load_library()
+    lib.ccn_internal_set_conv_variant.restype = ctypes.c_int
+    B, H, W = 8, 200, 168
+    g = torch.Generator("cpu").manual_seed(3)
+    x = to_dev(torch.randn((B, 3, H, W), generator=g)); z = to_dev(synth.synth_z(B))
+    t = to_dev(np.array([999, 800, 650, 500, 350, 200, 50, 0], np.int64))
+    old = lib.ccn_internal_set_conv_variant(3)
+    try:
+        e_fr = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")(x, z, t)
+        lib.ccn_internal_set_conv_variant(4)
+        e_pr = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")(x, z, t)
+    finally:
+        lib.ccn_internal_set_conv_variant(old)
+    e32 = make_net(c2_sd, 128, (1, 2, 2))(x, z, t)
+    assert torch.isfinite(e_pr).all()
+    d_kernels, d_fp32, d_fr32 = maxerr(e_pr, e_fr), maxerr(e_pr, e32), maxerr(e_fr, e32)
+    print(f"ragged 200x168 bf16: persistent vs free-running {d_kernels:.3e}; vs fp32 {d_fp32:.3e} (free-running vs fp32 {d_fr32:.3e})")
+    assert d_kernels < 8e-3 and d_fp32 < 2e-2, (d_kernels, d_fp32)
+    # image borders: the rows / columns covered by partial tiles must be as accurate as the interior
+    edge = max(maxerr(e_pr[:, :, -4:, :], e32[:, :, -4:, :]), maxerr(e_pr[:, :, :, -8:], e32[:, :, :, -8:]))
+    assert edge < 2e-2, edge
