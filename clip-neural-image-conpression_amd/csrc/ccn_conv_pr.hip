@@ -455,8 +455,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
+#ifndef PR_D
+#define PR_D 9
+#endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
-static pr_fn_t pick_pr(bool res) { return res ? (pr_fn_t)conv_pr_kernel<9, 6, true> : (pr_fn_t)conv_pr_kernel<9, 6, false>; }
+static pr_fn_t pick_pr(bool res) { return res ? (pr_fn_t)conv_pr_kernel<9, PR_D, true> : (pr_fn_t)conv_pr_kernel<9, PR_D, false>; }
 
 bool conv_pr_supported(int kind, int bn, int th) { return kind == KIND_C3S1 && bn == 128 && th == 8; }
 

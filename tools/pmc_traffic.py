@@ -13,7 +13,9 @@ def total(d, counter, pred):
             if r["Counter_Name"] == counter and pred(r["Kernel_Name"]):
                 tot += float(r["Counter_Value"]); n += 1
     return tot, n
-is_c3 = lambda k: "conv_ws_kernel" in k and "Li9E" in k           # 3x3 s1 family (NTAPS = 9)
+# 3x3 stride-1 family: the persistent kernel (conv_pr_kernel<9, ...>) plus the warp-specialised / free-running kernels
+# instantiated with NTAPS = 9 (the 32-pixel-level layers and any shape the persistent kernel does not take)
+is_c3 = lambda k: ("conv_pr_kernel" in k and ("<9," in k or "ILi9E" in k)) or (("conv_ws_kernel" in k or "conv_fr_kernel" in k) and "Li9E" in k)
 f, nf = total(fetch_dir, "FETCH_SIZE", is_c3)
 w, nw = total(write_dir, "WRITE_SIZE", is_c3)
 assert nf == nw and nf > 0, (nf, nw)
