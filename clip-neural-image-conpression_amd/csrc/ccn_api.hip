@@ -313,6 +313,22 @@ int pack_stem(ccn_handle_s* h, ConvW& cw, const std::string& name)      // Conv2
     const int K = cw.Cin * 9;
     int rc = pack_and_upload(h, cw, 1, [&](int, int o, int k) { return k < K ? w[(size_t)o * K + k] : 0.f; });
     if (rc) return rc;
+    if (stem2_supported(h->cfg.dtype, cw.Cin, cw.Cout, h->G)) {
+        // fragment order for ccn_stem.hip: [Cout/32][k-step 2][lane = h*32 + r][8 bf16]; lane (r, h) holds output channel
+        // j*32 + r, k = 16 s + 8 h + e; k = K is the bias (multiplied by a constant-one im2col element)
+        const float* bias = h->host.at(name + ".bias").data();
+        const int nt = cw.Cout / 32;
+        std::vector<uint16_t> fr((size_t)nt * 2 * 64 * 8, 0);
+        for (int j = 0; j < nt; ++j)
+            for (int s = 0; s < 2; ++s)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = j * 32 + (ln & 31), k = 16 * s + 8 * (ln >> 5) + e;
+                        const float v = k < K ? w[(size_t)o * K + k] : (k == K ? bias[o] : 0.f);
+                        fr[(((size_t)j * 2 + s) * 64 + ln) * 8 + e] = f2bf_host(v);
+                    }
+        if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
+    }
     return upload_f32(h, name + ".bias", &cw.bias);
 }
 
@@ -393,12 +409,16 @@ struct PlanBuilder {
         if (!pr) a.wfrag = nullptr;
         a.use_pr = pr ? 1 : 0;
         if (pr) a.nslot *= 4;
+        const bool stem2 = is_stem && cw.wfrag && stem2_supported(h->cfg.dtype, cw.Cin, cw.Cout, h->G);
+        a.use_stem2 = stem2 ? 1 : 0;
+        if (stem2) { a.wfrag = cw.wfrag; a.nslot = 4 * stem2_blocks(in.H, in.W, nullptr); }   // one slot per wave
         a.film_bstride = film_stride;
         fill_taps(a, cw.kind);
         if (want_part) {
             out.part = (float2*)bump.take((size_t)B * a.G * a.nslot * sizeof(float2));
             out.n_sp = g.n_ty * g.n_tx * g.npar; out.n_nt = g.n_nt; out.bn = cw.BN;
             if (pr) { out.n_sp *= 4; out.pr = true; }       // one slot per producer wave
+            if (stem2) { out.n_sp = a.nslot; out.n_nt = 1; out.bn = 1 << 30; out.pr = true; }
         }
         a.part = out.part;
         a.bn = cw.BN;

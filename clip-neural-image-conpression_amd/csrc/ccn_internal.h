@@ -45,6 +45,7 @@ struct ConvArgs {
     int dbg;                // ablation switches for profiling (CCN_DBG env): 1 no A staging in loop, 2 no B staging, 4 no MFMA, 8 no epilogue
     int th;                 // tile rows of 32 pixels per workgroup (4; 8 for the large warp-specialised tiles)
     int use_pr;             // decided at plan time: this launch runs the persistent kernel (its GroupNorm slot layout differs)
+    int use_stem2;          // decided at plan time: dedicated bf16 stem kernel (ccn_stem.hip)
     int n_ty, n_tx, n_nt, nchunk, ntaps;
     int silu;               // SiLU after the prologue GroupNorm
     int cpg, G, nslot;      // output GroupNorm geometry
@@ -81,6 +82,11 @@ bool conv_pr_supported(int kind, int bn, int th);
 bool conv_pr_selected(int dtype, int kind, int bn, int th);   // supported and chosen by the variant switch
 hipError_t conv_pr_prepare();
 hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s);
+
+// dedicated stem kernel (ccn_stem.hip): bf16 mode, K = img_ch*9 <= 31, Cout 32/64/128; weights + bias in fragment order in wfrag
+bool stem2_supported(int dtype, int cin, int cout, int G);
+int stem2_blocks(int H, int W, int* upw_out);
+hipError_t launch_stem2(const ConvArgs& a, hipStream_t s);
 
 // GroupNorm-apply + SiLU as its own pass (NHWC T -> NHWC T).  Used in front of convs whose input is re-staged by
 // several N tiles (Cout >= 256): the transform then runs once per element instead of once per (N tile x halo).
