@@ -486,19 +486,45 @@ struct PlanBuilder {
         return o;
     }
 
+    // the same pass with the finalize of `t`'s GroupNorm folded in (no gn() launch, no scale/shift table)
+    TensorRef preact_fused(const TensorRef& t, const NormW& n)
+    {
+        TensorRef o = new_tensor(t.C, t.H, t.W);
+        const int dtype = h->cfg.dtype, Bc = B, HW = t.H * t.W, C = t.C;
+        const int G = groups_for(t.C), cpg = t.C / G;
+        const double count = (double)cpg * t.H * t.W;
+        const float2* part = t.part; const int n_sp = t.n_sp, n_nt = t.n_nt, bn = t.bn;
+        const float* gamma = n.gamma; const float* beta = n.beta;
+        const void* src = t.p; void* dst = o.p;
+        Launch L{F_LAYOUT, 0.0, 2.0 * B * HW * (double)C * h->elem, nullptr};
+        L.fn = [=](hipStream_t s, const StepCtx&) -> hipError_t {
+            return launch_gn_act_fused(dtype, src, dst, Bc, HW, C, part, G, n_sp, n_nt, bn, cpg, count, gamma, beta, 1e-5f, s);
+        };
+        plan->ops.push_back(std::move(L));
+        return o;
+    }
+
     // x + conv2(SiLU(GN2(FiLM(conv1(SiLU(GN1(x))))))) -- models/blocks.py:40-44
     TensorRef resblock(const ResW& r, const TensorRef& x, bool out_feeds_gn, int film_off = -2)
     {
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256;
-        const float2* ab1 = gn(x, r.n1);
+        static const bool fuse_act = !getenv("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
+        const bool f1 = pre && fuse_act && x.part, f2 = pre && fuse_act;
         TensorRef y = new_tensor(r.C, x.H, x.W);
-        if (pre) { TensorRef xa = preact(x, ab1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
-        else conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
+        if (f1) { TensorRef xa = preact_fused(x, r.n1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
+        else {
+            const float2* ab1 = gn(x, r.n1);
+            if (pre) { TensorRef xa = preact(x, ab1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
+            else conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
+        }
         plan->named[r.prefix + ".film"] = y;
-        const float2* ab2 = gn(y, r.n2);
         TensorRef o = new_tensor(r.C, x.H, x.W);
-        if (pre) { TensorRef ya = preact(y, ab2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
-        else conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
+        if (f2) { TensorRef ya = preact_fused(y, r.n2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
+        else {
+            const float2* ab2 = gn(y, r.n2);
+            if (pre) { TensorRef ya = preact(y, ab2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
+            else conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
+        }
         plan->named[r.prefix] = o;
         return o;
     }

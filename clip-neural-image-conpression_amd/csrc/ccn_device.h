@@ -140,9 +140,10 @@ __device__ __forceinline__ float2 part_load(const float2* p)
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
-// scale/shift of every channel of group g of sample b from its partial sums; one wave per group, fixed summation order
-__device__ __forceinline__ void gn_reduce_group(const float2* part, int b, int g, int G, int nslot, int n_nt, int bn, int cpg, int C,
-                                                double count, const float* gamma, const float* beta, float eps, float2* ab, int lane)
+// mean and 1/sqrt(var + eps) of group g of sample b from its partial sums; one wave per group, fixed summation order;
+// every lane returns the result
+__device__ __forceinline__ void gn_group_stats(const float2* part, int b, int g, int G, int nslot, int n_nt, int bn, int cpg,
+                                               double count, float eps, int lane, double& mean, double& rstd)
 {
     const int jlo = (g * cpg) / bn, jhi = ((g + 1) * cpg - 1) / bn, nj = jhi - jlo + 1;
     const int n_sp = nslot / n_nt, ne = n_sp * nj;
@@ -155,10 +156,18 @@ __device__ __forceinline__ void gn_reduce_group(const float2* part, int b, int g
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
-    const double mean = s1 / count;
+    mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
+    rstd = 1.0 / sqrt(var + (double)eps);
+}
+
+// scale/shift of every channel of group g of sample b from its partial sums
+__device__ __forceinline__ void gn_reduce_group(const float2* part, int b, int g, int G, int nslot, int n_nt, int bn, int cpg, int C,
+                                                double count, const float* gamma, const float* beta, float eps, float2* ab, int lane)
+{
+    double mean, rstd;
+    gn_group_stats(part, b, g, G, nslot, n_nt, bn, cpg, count, eps, lane, mean, rstd);
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
         const double sc = (double)gamma[c] * rstd;
         // pair-interleaved: channels (2p, 2p+1) -> {scale, scale, shift, shift} (see GnCoef::load)

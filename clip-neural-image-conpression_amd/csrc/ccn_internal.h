@@ -92,6 +92,9 @@ hipError_t launch_stem2(const ConvArgs& a, hipStream_t s);
 // several N tiles (Cout >= 256): the transform then runs once per element instead of once per (N tile x halo).
 bool conv_wants_preact(int kind, int bn, int n_nt);
 hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, int B, int HW, int C, hipStream_t s);
+// the same with the GroupNorm finalize of the input folded in (partial sums -> scale/shift inside every workgroup)
+hipError_t launch_gn_act_fused(int dtype, const void* x, void* y, int B, int HW, int C, const float2* part, int G, int n_sp, int n_nt,
+                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s);
 
 // ---- GroupNorm finalize: partial sums -> per-(b,channel) scale/shift --------------------------------
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C,

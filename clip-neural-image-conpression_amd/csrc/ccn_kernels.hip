@@ -502,6 +502,60 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const T* __restrict__ x, co
         if (p < HW) *(u32x4*)(y + ((size_t)b * HW + p) * C + sl * EPC) = gk.template apply<true>(v[k]);
     }
 }
+// The same pass with the GroupNorm finalize folded in: every workgroup first reduces the producer's partial sums of its
+// sample (G groups x a few hundred slots, L2 resident; same summation order as gn_finalize_kernel, so the same bits) and
+// forms its threads' scale/shift in registers -- one launch and one ~5 us dependency step less per pre-activated conv.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_act_fused_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C,
+                                                            const float2* __restrict__ part, int G, int nslot, int n_nt, int bn, int cpg,
+                                                            double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps)
+{
+    constexpr int EPC = Vec16<T>::EPC;
+    __shared__ double st[64][2];
+    const int nsl = C / EPC, pstep = 256 / nsl;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sl = tid % nsl, pp = tid / nsl;
+    const int p0 = blockIdx.x * 4 * pstep + pp;
+    const bool act = pp < pstep;
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // the data loads fly while the statistics are reduced
+        const int p = p0 + k * pstep;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (act && p < HW) v[k] = *(const u32x4*)(x + ((size_t)b * HW + p) * C + sl * EPC);
+    }
+    for (int g = wave; g < G; g += 4) {
+        double mean, rstd;
+        gn_group_stats(part, b, g, G, nslot, n_nt, bn, cpg, count, eps, lane, mean, rstd);
+        if (lane == 0) { st[g][0] = mean; st[g][1] = rstd; }
+    }
+    __syncthreads();
+    if (!act) return;
+    GnCoef<T> gk;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = sl * EPC + e, g = c / cpg;
+        const double sc = (double)gamma[c] * st[g][1];
+        gk.a[e] = (float)sc; gk.c[e] = (float)((double)beta[c] - st[g][0] * sc);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k * pstep;
+        if (p < HW) *(u32x4*)(y + ((size_t)b * HW + p) * C + sl * EPC) = gk.template apply<true>(v[k]);
+    }
+}
+hipError_t launch_gn_act_fused(int dtype, const void* x, void* y, int B, int HW, int C, const float2* part, int G, int n_sp, int n_nt,
+                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s)
+{
+    const int epc = dtype == 0 ? 4 : 8, nsl = C / epc;
+    if (nsl > 256 || nsl <= 0 || G > 64) return hipErrorInvalidValue;
+    const int pstep = 256 / nsl;
+    const dim3 grid((HW + 4 * pstep - 1) / (4 * pstep), B);
+    if (dtype == 0) hipLaunchKernelGGL(gn_act_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps);
+    else hipLaunchKernelGGL(gn_act_fused_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, int B, int HW, int C, hipStream_t s)
 {
     const int epc = dtype == 0 ? 4 : 8, nsl = C / epc;
