@@ -303,6 +303,26 @@ int pack_convT(ccn_handle_s* h, ConvW& cw, const std::string& name)     // ConvT
     const int I = cw.Cin, O = cw.Cout;
     int rc = pack_and_upload(h, cw, 16, [&](int t, int o, int i) { return i < I ? w[((size_t)i * O + o) * 16 + t] : 0.f; });
     if (rc) return rc;
+    if (cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
+        // fragment order for ccn_conv_pr.hip: [parity][chunk][Cout_pad/32][tap 0..3][kk][lane][8]; tap order and kernel
+        // indices as in fill_taps (even outputs <- k in {1, 3}, odd <- {0, 2})
+        static const int kk2[2][2] = {{1, 3}, {0, 2}};
+        const int nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32;
+        std::vector<uint16_t> fr((size_t)4 * nch * n32 * 4 * 4 * 64 * 8, 0);
+        size_t p = 0;
+        for (int par = 0; par < 4; ++par)
+            for (int c = 0; c < nch; ++c)
+                for (int nn = 0; nn < n32; ++nn)
+                    for (int t = 0; t < 4; ++t)
+                        for (int q = 0; q < 4; ++q)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int e = 0; e < 8; ++e, ++p) {
+                                    const int o = nn * 32 + (ln & 31), i = c * cke + (2 * q + (ln >> 5)) * 8 + e;
+                                    const int wt = kk2[par >> 1][t >> 1] * 4 + kk2[par & 1][t & 1];
+                                    fr[p] = (o < O && i < I) ? f2bf_host(w[((size_t)i * O + o) * 16 + wt]) : 0;
+                                }
+        if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
+    }
     return upload_f32(h, name + ".bias", &cw.bias);
 }
 int pack_stem(ccn_handle_s* h, ConvW& cw, const std::string& name)      // Conv2d weight (O, img_ch, 3, 3) as K = I*9

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         auto prep = [&]() __attribute__((always_inline)) {
             const int tile = vb + rq_ti * grid;
             q_tv = tile < ntiles;
-            const int sp = (q_tv ? tile : vb) / a.n_nt;
+            const int sp = (q_tv ? tile : vb) / (a.n_nt * a.npar);         // tile = ((spatial tile) * npar + parity) * n_nt + N tile
             const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = rq_c;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
         u32x4 rr[RES ? 2 : 1][4];                // residual rows, batches of 4 items (two tile rows), two batches in flight
         f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
-        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0;
+        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0;
         unsigned e_base = 0;
         int e_rows = 0;                          // wave-uniform: valid rows of the tile
         unsigned e_m0 = OOB, e_m1 = OOB;         // 0 when this thread's first / second column (and its octet) is inside the tensor
@@ -202,17 +202,20 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // laundered copy of e_base: otherwise the 16 offsets are computed once per tile and kept live across dump() and the barrier
         auto item_off = [&](unsigned eb, int it) __attribute__((always_inline)) -> unsigned {
             const unsigned rmask = (it >> 1) < e_rows ? 0u : OOB;                 // wave-uniform
-            return (eb + (unsigned)(it >> 1) * (unsigned)(a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.Cout * (int)sizeof(T)))
+            return (eb + (unsigned)(it >> 1) * (unsigned)(a.OS * a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.OS * a.Cout * (int)sizeof(T)))
                    | ((it & 1) ? e_m1 : e_m0) | rmask;
         };
         // during the tile's last chunk: decode the tile
         auto epi_setup = [&](int tile) __attribute__((always_inline)) {
             e_nt = tile % a.n_nt;
-            const int sp = tile / a.n_nt;
+            const int t2 = tile / a.n_nt;
+            e_par = t2 % a.npar;
+            const int sp = t2 / a.npar;
             e_tx = sp % a.n_tx; e_ty = (sp / a.n_tx) % a.n_ty; e_b = sp / (a.n_tx * a.n_ty);
             const int nb = e_nt * BN + o16 * 8;
             const bool nvalid = nb < a.Cout;
-            e_base = (unsigned)(((e_b * a.Hout + e_ty * TH) * a.Wout + e_tx * 32 + pr) * a.Cout + nb) * (unsigned)sizeof(T);
+            // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
+            e_base = (unsigned)(((e_b * a.Hout + e_ty * TH * a.OS + (e_par >> 1)) * a.Wout + (e_tx * 32 + pr) * a.OS + (e_par & 1)) * a.Cout + nb) * (unsigned)sizeof(T);
             e_rows = a.MH - e_ty * TH;
             e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
             e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                         const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
                         float t1 = 0.f, t2 = 0.f;
                         for (int c = clo; c < chi; ++c) { t1 += chs[(c - n0) * 2]; t2 += chs[(c - n0) * 2 + 1]; }
-                        const int slot = ((e_ty * a.n_tx + e_tx) * 4 + pw) * a.n_nt + e_nt;
+                        const int slot = (((e_ty * a.n_tx + e_tx) * a.npar + e_par) * 4 + pw) * a.n_nt + e_nt;
                         part_store(a.part + (size_t)(e_b * a.G + g) * a.nslot + slot, t1, t2);
                     }
                 }
@@ -354,12 +357,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // weight fragments: [chunk][Cout_pad/32][tap][kk][lane] x 16 B (host-packed); this wave owns columns nt*4 + wn*2 + {0,1}
     const int n32 = a.Cout_pad / 32;
     constexpr unsigned COLB = NSTEP * 1024;                        // bytes of one 32-channel column of one chunk
-    const unsigned wtotal = (unsigned)((size_t)a.nchunk * n32 * COLB);
+    const unsigned wtotal = (unsigned)((size_t)a.npar * a.nchunk * n32 * COLB);
     const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
-        const int nt = tile % a.n_nt;
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(chunk * n32 + nt * 4 + wn * NF) * COLB));
+        const int nt = tile % a.n_nt, par = (tile / a.n_nt) % a.npar;      // ConvTranspose: [parity][chunk][column][tap][kk][lane]
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((par * a.nchunk + chunk) * n32 + nt * 4 + wn * NF) * COLB));
     };
     u32x4 bq[D][NF];
     {
@@ -378,6 +381,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int tile = vb + ti * grid;
         const int tile_next = tile + grid < ntiles ? tile + grid : tile;
+        int toffs[NTAPS == 9 ? 1 : NTAPS];                         // ConvTranspose: the parity's 2x2 taps (wave-uniform)
+        if constexpr (NTAPS != 9) {
+            const int par = (tile / a.n_nt) % a.npar;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + a.tapinfo_dx(par * 4 + t);
+        }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             auto frag = [&](int j, u32x4* av_) __attribute__((always_inline)) {
                 const int tt = j >> 2, kk = j & 3;
                 if (kk == 0) {
-                    const int toff = NTAPS == 9 ? (tt / 3 - 1) * HPITCH + (tt % 3 - 1) : 0;
+                    const int toff = NTAPS == 9 ? (tt / 3 - 1) * HPITCH + (tt % 3 - 1) : toffs[NTAPS == 9 ? 0 : tt];
 #pragma unroll
                     for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toff);
                 }
@@ -459,17 +468,23 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #define PR_D 9
 #endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
-static pr_fn_t pick_pr(bool res) { return res ? (pr_fn_t)conv_pr_kernel<9, PR_D, true> : (pr_fn_t)conv_pr_kernel<9, PR_D, false>; }
+static pr_fn_t pick_pr(int ntaps, bool res)
+{
+    if (ntaps == 9) return res ? (pr_fn_t)conv_pr_kernel<9, PR_D, true> : (pr_fn_t)conv_pr_kernel<9, PR_D, false>;
+    return res ? (pr_fn_t)conv_pr_kernel<4, 8, true> : (pr_fn_t)conv_pr_kernel<4, 8, false>;
+}
 
-bool conv_pr_supported(int kind, int bn, int th) { return kind == KIND_C3S1 && bn == 128 && th == 8; }
+bool conv_pr_supported(int kind, int bn, int th) { return (kind == KIND_C3S1 || kind == KIND_CT4) && bn == 128 && th == 8; }
 
 static int g_cus = 0;
 hipError_t conv_pr_prepare()
 {
-    hipError_t e = hipFuncSetAttribute((const void*)pick_pr(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)pick_pr(true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    for (int ntaps = 4; ntaps <= 9; ntaps += 5)
+        for (int res = 0; res < 2; ++res) {
+            e = hipFuncSetAttribute((const void*)pick_pr(ntaps, res != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
+            if (e != hipSuccess) return e;
+        }
     int dev = 0;
     e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -497,8 +512,9 @@ extern "C" int ccn_internal_dump_stamps_pr(const char* path)
 
 hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
 {
-    if (dtype != 1 || !a.wfrag || a.npar != 1 || a.ntaps != 9 || a.th != 8 || a.OS != 1 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
-    const int ntiles = a.B * a.n_ty * a.n_tx * a.n_nt;
+    const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
+    if (dtype != 1 || !a.wfrag || !(c3 || ct) || a.th != 8 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
+    const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt;
     static const int cap = getenv("CCN_PR_GRID") ? atoi(getenv("CCN_PR_GRID")) : 0;
     int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);
     if (grid > ntiles) grid = ntiles;
@@ -509,7 +525,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
         g_stamp_grid = (unsigned)grid;
         d.stamps = g_stamps;
     } else d.stamps = nullptr;
-    hipLaunchKernelGGL(pick_pr(a.res != nullptr), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
+    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res != nullptr), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
     return hipGetLastError();
 }
 
