@@ -270,6 +270,26 @@ int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2
     const int I = cw.Cin;
     int rc = pack_and_upload(h, cw, 9, [&](int t, int o, int i) { return i < I ? w[((size_t)o * I + i) * 9 + t] : 0.f; });
     if (rc) return rc;
+    if (cw.kind == KIND_C3S2 && cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
+        // plane-pass order for the persistent kernel (ccn_conv_pr.hip, NTAPS == 2): [channel chunk][pass 0..4][Cout_pad/32][tap slot 0..1]
+        // [kk][lane][8]; slot -> (dy, dx) of the 3x3 kernel, the tenth slot is zero
+        static const int tdy[5][2] = {{0, 0}, {2, 2}, {0, 2}, {1, 1}, {1, -1}}, tdx[5][2] = {{0, 2}, {0, 2}, {1, 1}, {0, 2}, {1, -1}};
+        const int nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32, O = cw.Cout;
+        std::vector<uint16_t> fr((size_t)nch * 5 * n32 * 2 * 4 * 64 * 8, 0);
+        size_t p = 0;
+        for (int c = 0; c < nch; ++c)
+            for (int pass = 0; pass < 5; ++pass)
+                for (int nn = 0; nn < n32; ++nn)
+                    for (int t = 0; t < 2; ++t)
+                        for (int q = 0; q < 4; ++q)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int e = 0; e < 8; ++e, ++p) {
+                                    const int o = nn * 32 + (ln & 31), i = c * cke + (2 * q + (ln >> 5)) * 8 + e;
+                                    const int dy = tdy[pass][t], dx = tdx[pass][t];
+                                    fr[p] = (dy >= 0 && o < O && i < I) ? f2bf_host(w[((size_t)o * I + i) * 9 + dy * 3 + dx]) : 0;
+                                }
+        if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
+    }
     if (cw.kind == KIND_C3S1 && cw.BN == 128) {
         // fragment order for ccn_conv_pr.hip: [chunk][Cout_pad/32][tap][kk][lane = h*32 + r][EPC]; lane (r, h) of column n32
         // holds output channel n32*32 + r, input channels chunk*cke + (2*kk + h)*EPC + e -- one wave load = 1 KiB contiguous
@@ -409,7 +429,14 @@ struct PlanBuilder {
     void conv(const ConvW& cw, int family, const TensorRef& in, TensorRef& out, const float2* gn_ab, int film_off,
               const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
     {
-        const ConvGeom g = conv_geom(cw, B, in.H, in.W);
+        ConvGeom g = conv_geom(cw, B, in.H, in.W);
+        // stride-2 convs: the 4-wave kernel works on 4-row tiles; the persistent kernel (bf16) takes them on 8-row tiles as soon
+        // as half the CUs get a tile (it is ~2.5x more efficient per tile)
+        const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+        const bool s2pr = cw.kind == KIND_C3S2 && cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, 8) && !gn_ab &&
+                          cw.Cin_pad / cke >= 2 && (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9 &&
+                          (long)B * ceil_div(g.MH, 8) * g.n_tx * g.n_nt >= 128;
+        if (s2pr) { g.th = 8; g.n_ty = ceil_div(g.MH, 8); }
         std::shared_ptr<ConvArgs> ap(new ConvArgs());
         ConvArgs& a = *ap;
         a.in = in.p; a.w = cw.w; a.wfrag = cw.wfrag; a.bias = cw.bias; a.out = out.p;
@@ -418,13 +445,13 @@ struct PlanBuilder {
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = cw.Cout; a.Cout_pad = cw.Cout_pad;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
         a.n_ty = g.n_ty; a.n_tx = g.n_tx; a.n_nt = g.n_nt; a.th = g.th;
-        const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
         a.nchunk = cw.Cin_pad / cke;
         a.silu = 1;
         a.G = groups_for(cw.Cout); a.cpg = cw.Cout / a.G;
         a.nslot = g.n_ty * g.n_tx * g.npar * g.n_nt;
         // the persistent kernel publishes one partial per producer wave (4 per tile)
-        const bool pr = cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 &&
+        if (s2pr) { a.nchunk = 5 * (cw.Cin_pad / cke); a.ntaps = 2; }   // plane passes (ccn_conv_pr.hip)
+        const bool pr = cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 && (cw.kind != KIND_C3S2 || s2pr) &&
                         (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
         if (!pr) a.wfrag = nullptr;
         a.use_pr = pr ? 1 : 0;

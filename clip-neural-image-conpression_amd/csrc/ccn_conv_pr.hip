@@ -53,6 +53,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     constexpr int TH = 8, BN = 128;
     constexpr int EPC = 8, CKE = 64;
     constexpr int NSTEP = NTAPS * 4;                           // step = tap * 4 + kk (one 16-byte K slice per lane half)
+    // NTAPS == 2: the stride-2 3x3 conv.  Its 9 taps fall on the four parity planes P[py][px](i, j) = in(2i+py, 2j+px) of the
+    // input (out(y,x) needs rows 2y-1, 2y, 2y+1 = plane 1 at i = y-1, plane 0 at y, plane 1 at y), so it is run as a stride-1
+    // problem whose "Cin chunks" are (channel chunk, plane pass) pairs with two taps each: the producers stage a 10 x 34
+    // halo tile of ONE plane per pass (input stride 2), the consumers see effective chunks of 8 steps.  Five passes per
+    // channel chunk (plane (1,1) twice, the tenth tap slot has zero weights):
+    //   pass 0: plane (1,1), taps (dy,dx) (0,0) (0,2) at offsets (-1,-1) (-1,0)      pass 1: plane (1,1), (2,0) (2,2) at (0,-1) (0,0)
+    //   pass 2: plane (1,0), (0,1) (2,1) at (-1,0) (0,0)      pass 3: plane (0,1), (1,0) (1,2) at (0,-1) (0,0)      pass 4: plane (0,0), (1,1) at (0,0)
+    constexpr bool S2 = NTAPS == 2;
+    constexpr int IS = S2 ? 2 : 1;                             // input stride of the staged plane
     static_assert(NSTEP % D == 0, "the register ring must wrap at the chunk boundary");
     using L = PrLds;
     constexpr int HPITCH = L::HPITCH;
@@ -129,37 +138,41 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = rq_c;
-            const int cb = q_c * CKE + ck * EPC;
+            const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gkn.load(a.gn_ab + (size_t)q_b * a.Cin + (cv ? cb : 0), gn && cv);
             if (++rq_c == a.nchunk) { rq_c = 0; ++rq_ti; }
         };
         auto issue = [&]() __attribute__((always_inline)) {
             const int b = q_b, iy0 = q_iy0, ix0 = q_ix0;
-            const int cb = q_c * CKE + ck * EPC;
+            const int cc = S2 ? q_c / 5 : q_c;                                     // channel chunk
+            const int pass = S2 ? q_c - cc * 5 : 0;
+            const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
+            const int cb = cc * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gk = gkn;
-            const unsigned coff = (unsigned)((size_t)(cv ? q_c : 0) * CKE * sizeof(T));
+            const unsigned coff = (unsigned)((size_t)(cv ? cc : 0) * CKE * sizeof(T));
             const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + coff), 0, in_bytes - coff, 0x00020000);
-            const int rs = a.Win * a.Cin * (int)sizeof(T);                        // row stride in bytes
-            const int ix = ix0 + pcol;
-            colv = cv && ix >= 0 && ix < a.Win;
+            const int rs = IS * a.Win * a.Cin * (int)sizeof(T);                   // row stride of the staged plane in bytes
+            const int ixr = IS * (ix0 + pcol) + px;                               // input column of this thread's halo column
+            colv = cv && ixr >= 0 && ixr < a.Win;
             // branch-free validity: OR an out-of-range constant into the offset (an invalid row or column may have produced
             // any value, negative included -- all of them stay past num_records once the mask is ORed in)
             const unsigned cmask = colv ? 0u : OOB;
-            const int base = ((b * a.Hin + iy0) * a.Win + ix) * a.Cin * (int)sizeof(T) + ck * 16;
+            const int base = ((b * a.Hin + IS * iy0 + py) * a.Win + ixr) * a.Cin * (int)sizeof(T) + ck * 16;
             rowm = 0;
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const bool rv = iy0 + i >= 0 && iy0 + i < a.Hin;                  // wave-uniform
+                const int iyr = IS * (iy0 + i) + py;
+                const bool rv = iyr >= 0 && iyr < a.Hin;                          // wave-uniform
                 const unsigned rmask = rv ? 0u : OOB;
                 rowm |= rv ? (1u << i) : 0u;
                 areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask | rmask, 0, 0);
             }
             {
-                const int iy = iy0 + xrow, ixx = ix0 + xcol;
-                xv = xthr && cv && iy >= 0 && iy < a.Hin && ixx < a.Win;
-                const int off = ((b * a.Hin + iy) * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
+                const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
+                xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
+                const int off = ((b * a.Hin + iyr) * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
                 areg[10] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
             }
         };
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int tile = vb + ti * grid;
         const int tile_next = tile + grid < ntiles ? tile + grid : tile;
         int toffs[NTAPS == 9 ? 1 : NTAPS];                         // ConvTranspose: the parity's 2x2 taps (wave-uniform)
-        if constexpr (NTAPS != 9) {
+        if constexpr (NTAPS == 4) {
             const int par = (tile / a.n_nt) % a.npar;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + a.tapinfo_dx(par * 4 + t);
@@ -397,6 +410,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const unsigned wb_cur = wbase_of(tile, chunk);
             const unsigned wb_nxt = chunk + 1 < a.nchunk ? wbase_of(tile, chunk + 1) : wbase_of(tile_next, 0);
             const int bufoff = (k & 1) * L::A_BYTES;
+            if constexpr (S2) {                                    // this pass's two taps inside the staged plane (table in the header)
+                const int pass = chunk % 5;
+                toffs[0] = (pass == 0 || pass == 2) ? -HPITCH - (pass == 0 ? 1 : 0) : ((pass == 1 || pass == 3) ? -1 : 0);
+                toffs[1] = pass == 0 ? -HPITCH : 0;
+            }
 #pragma unroll
             for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop
             u32x4 av[2][MF];
@@ -471,16 +489,17 @@ typedef void (*pr_fn_t)(const ConvArgs, int);
 static pr_fn_t pick_pr(int ntaps, bool res)
 {
     if (ntaps == 9) return res ? (pr_fn_t)conv_pr_kernel<9, PR_D, true> : (pr_fn_t)conv_pr_kernel<9, PR_D, false>;
+    if (ntaps == 2) return res ? (pr_fn_t)conv_pr_kernel<2, 8, true> : (pr_fn_t)conv_pr_kernel<2, 8, false>;
     return res ? (pr_fn_t)conv_pr_kernel<4, 8, true> : (pr_fn_t)conv_pr_kernel<4, 8, false>;
 }
 
-bool conv_pr_supported(int kind, int bn, int th) { return (kind == KIND_C3S1 || kind == KIND_CT4) && bn == 128 && th == 8; }
+bool conv_pr_supported(int kind, int bn, int th) { return (kind == KIND_C3S1 || kind == KIND_CT4 || kind == KIND_C3S2) && bn == 128 && th == 8; }
 
 static int g_cus = 0;
 hipError_t conv_pr_prepare()
 {
     hipError_t e = hipSuccess;
-    for (int ntaps = 4; ntaps <= 9; ntaps += 5)
+    for (int ntaps : {2, 4, 9})
         for (int res = 0; res < 2; ++res) {
             e = hipFuncSetAttribute((const void*)pick_pr(ntaps, res != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
             if (e != hipSuccess) return e;
@@ -512,8 +531,10 @@ extern "C" int ccn_internal_dump_stamps_pr(const char* path)
 
 hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
 {
+    // a.ntaps as the persistent kernel sees the layer: 9 (3x3 s1), 4 (ConvTranspose parity), 2 (3x3 s2 as plane passes, nchunk = 5 x channel chunks)
     const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
-    if (dtype != 1 || !a.wfrag || !(c3 || ct) || a.th != 8 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
+    const bool s2 = a.ntaps == 2 && a.npar == 1 && a.OS == 1 && !a.gn_ab && (a.nchunk % 5) == 0;
+    if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || a.th != 8 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
     const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt;
     static const int cap = getenv("CCN_PR_GRID") ? atoi(getenv("CCN_PR_GRID")) : 0;
     int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);

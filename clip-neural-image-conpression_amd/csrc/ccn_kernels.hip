@@ -448,6 +448,7 @@ bool conv_pr_selected(int dtype, int kind, int bn, int th)
 hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream_t s)
 {
     if (a.use_stem2) return launch_stem2(a, s);
+    if (a.use_pr && kind == KIND_C3S2) return launch_conv_pr(dtype, a, s);
     if (conv_ws_enabled() && conv_ws_supported(kind, bn)) {
         static const int dbg = getenv("CCN_DBG") ? atoi(getenv("CCN_DBG")) : 0;
         ConvArgs d = a; d.dbg = dbg;
