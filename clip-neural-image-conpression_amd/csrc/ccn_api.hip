@@ -551,10 +551,23 @@ struct PlanBuilder {
         return o;
     }
 
+    // the 3x3 s1 conv `cw` on an H x W input will run on the persistent kernel (same conditions as conv())
+    bool will_use_pr(const ConvW& cw, int H, int W) const
+    {
+        const ConvGeom g = conv_geom(cw, B, H, W);
+        const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+        return cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 &&
+               (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
+    }
+
     // x + conv2(SiLU(GN2(FiLM(conv1(SiLU(GN1(x))))))) -- models/blocks.py:40-44
     TensorRef resblock(const ResW& r, const TensorRef& x, bool out_feeds_gn, int film_off = -2)
     {
-        const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256;
+        // pre-pass only where the conv kernel would redo the transform per N tile AND has no idle VALU for it: the persistent
+        // kernel's producers absorb it (CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
+        static const bool preact_pr = getenv("CCN_PREACT_PR") != nullptr;
+        const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
+                         (preact_pr || !will_use_pr(r.c1, x.H, x.W));
         static const bool fuse_act = !getenv("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
         const bool f1 = pre && fuse_act && x.part, f2 = pre && fuse_act;
         TensorRef y = new_tensor(r.C, x.H, x.W);
