@@ -120,6 +120,7 @@ struct Plan {
     int32_t* ts_dev = nullptr;
     float *temb = nullptr, *t1 = nullptr, *tp = nullptr, *zp = nullptr, *film = nullptr;
     float *zbuf = nullptr, *xstate = nullptr;
+    std::vector<std::pair<void*, size_t>> zero_once;   // regions zeroed when the plan is created (split-K hand-off flags)
     unsigned* counters = nullptr;        // arrival counters of the fused GroupNorm finalizes, [kMaxNorms][B], zero at rest
     int n_counters = 0;
     std::vector<int32_t> ts_keep;        // host copy of the last timestep table (source of the async upload)
@@ -425,6 +426,26 @@ struct PlanBuilder {
     float2* new_ab(int C) { return (float2*)bump.take((size_t)B * C * sizeof(float2)); }
     int groups_for(int C) const { return C < h->G ? C : h->G; }
 
+    // 2 when the layer should run split-K on the persistent kernel (see conv()), else 1
+    int split_k_for(const ConvW& cw, const ConvGeom& g, bool has_gn, bool s2pr) const
+    {
+        static const bool off = getenv("CCN_NO_SPLITK") != nullptr;
+        if (off || h->cfg.dtype != CCN_DTYPE_BF16 || !cw.wfrag || cw.BN != 128) return 1;
+        // Measured at C2: a single-tile-per-workgroup launch of the persistent kernel carries ~25 us of fixed cost (cold first
+        // chunk, serial last epilogue, hand-off), so halving the K loop of the 32-pixel 3x3 s1 layers (56 us) does not beat the
+        // 4-row kernel (53 us); it does help the stride-2 conv into that level (63 -> 56 us), whose alternative is 128 tiles.
+        // CCN_SPLITK_S1=1 enables it for the stride-1 layers too.
+        static const bool s1_too = getenv("CCN_SPLITK_S1") != nullptr;
+        if (!((cw.kind == KIND_C3S1 && s1_too) || (cw.kind == KIND_C3S2 && s2pr))) return 1;
+        if (!conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, 8)) return 1;
+        const int cke = 64;
+        const long tiles8 = (long)B * ceil_div(g.MH, 8) * g.n_tx * g.npar * g.n_nt;
+        int nchunk = cw.Cin_pad / cke;
+        if (cw.kind == KIND_C3S2) { if ((nchunk & 1)) return 1; nchunk *= 5; }
+        (void)has_gn;
+        return (tiles8 >= 32 && tiles8 <= 128 && nchunk >= 4 && (nchunk & 1) == 0) ? 2 : 1;
+    }
+
     // conv launch; `want_part`: also emit the partial sums of the output's GroupNorm
     void conv(const ConvW& cw, int family, const TensorRef& in, TensorRef& out, const float2* gn_ab, int film_off,
               const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
@@ -437,6 +458,10 @@ struct PlanBuilder {
                           cw.Cin_pad / cke >= 2 && (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9 &&
                           (long)B * ceil_div(g.MH, 8) * g.n_tx * g.n_nt >= 128;
         if (s2pr) { g.th = 8; g.n_ty = ceil_div(g.MH, 8); }
+        // small layers (at most #CUs/2 tiles of 8 rows: the 32-pixel level at C2): 8-row tiles on the persistent kernel with the
+        // Cin chunks split over two workgroups per tile instead of 4-row tiles on the LDS-bound kernel
+        const int ksplit = split_k_for(cw, g, gn_ab != nullptr, s2pr);
+        if (ksplit == 2 && g.th != 8) { g.th = 8; g.n_ty = ceil_div(g.MH, 8); }
         std::shared_ptr<ConvArgs> ap(new ConvArgs());
         ConvArgs& a = *ap;
         a.in = in.p; a.w = cw.w; a.wfrag = cw.wfrag; a.bias = cw.bias; a.out = out.p;
@@ -455,6 +480,14 @@ struct PlanBuilder {
                         (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
         if (!pr) a.wfrag = nullptr;
         a.use_pr = pr ? 1 : 0;
+        a.ksplit = 1;
+        if (pr && ksplit == 2) {
+            a.ksplit = 2;
+            a.kpart = bump.take((size_t)B * g.Hout * g.Wout * cw.Cout * h->elem);
+            const size_t fbytes = (size_t)B * g.n_ty * g.n_tx * g.npar * g.n_nt * 4 * sizeof(unsigned);
+            a.kflag = (unsigned*)bump.take(fbytes);
+            if (a.kflag) plan->zero_once.push_back({a.kflag, fbytes});
+        }
         if (pr) a.nslot *= 4;
         const bool stem2 = is_stem && cw.wfrag && stem2_supported(h->cfg.dtype, cw.Cin, cw.Cout, h->G);
         a.use_stem2 = stem2 ? 1 : 0;
@@ -554,8 +587,9 @@ struct PlanBuilder {
     // the 3x3 s1 conv `cw` on an H x W input will run on the persistent kernel (same conditions as conv())
     bool will_use_pr(const ConvW& cw, int H, int W) const
     {
-        const ConvGeom g = conv_geom(cw, B, H, W);
+        ConvGeom g = conv_geom(cw, B, H, W);
         const int cke = h->cfg.dtype == CCN_DTYPE_BF16 ? 64 : 32;
+        if (split_k_for(cw, g, true, false) == 2) g.th = 8;
         return cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 &&
                (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
     }
@@ -567,7 +601,7 @@ struct PlanBuilder {
         // kernel's producers absorb it (CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
         static const bool preact_pr = getenv("CCN_PREACT_PR") != nullptr;
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
-                         (preact_pr || !will_use_pr(r.c1, x.H, x.W));
+                         (preact_pr || r.c1.Cout_pad / r.c1.BN >= 4 || !will_use_pr(r.c1, x.H, x.W));
         static const bool fuse_act = !getenv("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
         const bool f1 = pre && fuse_act && x.part, f2 = pre && fuse_act;
         TensorRef y = new_tensor(r.C, x.H, x.W);
@@ -676,6 +710,7 @@ int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t w
     if (rc) return rc;
     if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(p->bytes));
     HIPCHK(hipMemset(p->counters, 0, (size_t)kMaxNorms * B * 4));          // arrival counters start (and are left) at zero
+    for (auto& z : p->zero_once) HIPCHK(hipMemset(z.first, 0, z.second));
     if (h->plans.size() >= 8) h->plans.erase(h->plans.begin());
     *out = p.get();
     h->plans.push_back(std::move(p));

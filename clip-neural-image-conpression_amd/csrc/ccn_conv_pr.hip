@@ -43,11 +43,21 @@ static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 
 }  // namespace
 
-// RES: epilogue adds the residual tensor and ignores FiLM (ResBlock conv2); !RES: bias / FiLM only (conv1).  Separate
-// instantiations keep the producers' register footprint down: they hold either residual rows or FiLM vectors, never both.
-template <int NTAPS, int D, bool RES>
+// MODE 1 (RES): the epilogue adds the residual tensor and ignores FiLM (ResBlock conv2, ConvTranspose + skip); MODE 0: bias /
+// FiLM only (conv1, stride-2); MODE 2: MODE 0 for split-K launches (its second half adds the first half's partial tile, so it
+// needs residual registers too).  Separate instantiations keep the producers' register footprint down.
+//
+// Split-K (a.ksplit == 2; layers with at most #CUs/2 tiles -- the 32-pixel level at C2): virtual tile v = 2*tile + kh computes
+// the Cin chunks [kh*nchunk/2, (kh+1)*nchunk/2).  The kh = 0 half finishes its epilogue into the bf16 partial tensor `kpart`
+// (bias / FiLM / residual already applied) and raises one flag per producer wave (release, agent scope); the kh = 1 half
+// waits for that flag (bounded spin, acquire), adds the partial like a residual and writes the output and the GroupNorm
+// statistics.  Partner workgroups are neighbours in the virtual tile order (same XCD) and never wait on each other in the
+// other direction, so the launch cannot deadlock as long as its <= #CUs workgroups are co-resident.
+template <int NTAPS, int D, int MODE>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
+    constexpr bool RES = MODE == 1;                            // residual registers: MODE 1 always, MODE 2 in the second K half
+    constexpr bool RR = MODE != 0;
     typedef __bf16 T;
     constexpr int MF = 4, NF = 2;
     constexpr int TH = 8, BN = 128;
@@ -76,9 +86,13 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // pixel tile) then meet in the same L2.
     const int grid = (int)gridDim.x;
     const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
-    const int ntiles = grid_tiles;
+    const int ntiles = grid_tiles;                             // virtual tiles (x2 under split-K)
     const int my_tiles = (ntiles - vb + grid - 1) / grid;      // >= 1 (grid <= ntiles)
-    const int ktotal = my_tiles * a.nchunk;
+    const int ks = a.ksplit == 2 ? 2 : 1;
+    const int nck = a.nchunk / ks;                             // chunks per virtual tile
+    const int ktotal = my_tiles * nck;
+    auto vt_tile = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v >> 1) : v; };
+    auto vt_kh = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v & 1) : 0; };
 
     const unsigned char* const inb = (const unsigned char*)a.in;
     const bool gn = a.gn_ab != nullptr && !(a.dbg & 32);     // CCN_DBG=32: skip the transform (timing experiments only)
@@ -132,16 +146,17 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         int q_b = 0, q_iy0 = 0, q_ix0 = 0, q_c = 0;
         bool q_tv = false;
         auto prep = [&]() __attribute__((always_inline)) {
-            const int tile = vb + rq_ti * grid;
-            q_tv = tile < ntiles;
-            const int sp = (q_tv ? tile : vb) / (a.n_nt * a.npar);         // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+            const int v = vb + rq_ti * grid;
+            q_tv = v < ntiles;
+            const int tile = vt_tile(q_tv ? v : vb);
+            const int sp = tile / (a.n_nt * a.npar);                       // tile = ((spatial tile) * npar + parity) * n_nt + N tile
             const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
-            q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = rq_c;
+            q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = vt_kh(v) * nck + rq_c;
             const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gkn.load(a.gn_ab + (size_t)q_b * a.Cin + (cv ? cb : 0), gn && cv);
-            if (++rq_c == a.nchunk) { rq_c = 0; ++rq_ti; }
+            if (++rq_c == nck) { rq_c = 0; ++rq_ti; }
         };
         auto issue = [&]() __attribute__((always_inline)) {
             const int b = q_b, iy0 = q_iy0, ix0 = q_ix0;
@@ -205,9 +220,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const auto osrd = __builtin_amdgcn_make_buffer_rsrc((void*)outb, 0, out_bytes, 0x00020000);
         const auto rsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(resb ? resb : outb), 0, out_bytes, 0x00020000);
         float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
-        u32x4 rr[RES ? 2 : 1][4];                // residual rows, batches of 4 items (two tile rows), two batches in flight
+        u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
         f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
-        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0;
+        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0, e_kh = 0, e_tile = 0;
+        unsigned char* const kpartb = (unsigned char*)a.kpart;
         unsigned e_base = 0;
         int e_rows = 0;                          // wave-uniform: valid rows of the tile
         unsigned e_m0 = OOB, e_m1 = OOB;         // 0 when this thread's first / second column (and its octet) is inside the tensor
@@ -219,7 +235,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                    | ((it & 1) ? e_m1 : e_m0) | rmask;
         };
         // during the tile's last chunk: decode the tile
-        auto epi_setup = [&](int tile) __attribute__((always_inline)) {
+        auto epi_setup = [&](int v) __attribute__((always_inline)) {
+            const int tile = vt_tile(v);
+            e_kh = vt_kh(v); e_tile = tile;
             e_nt = tile % a.n_nt;
             const int t2 = tile / a.n_nt;
             e_par = t2 % a.npar;
@@ -233,16 +251,41 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
             e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
         };
+        // residual source of the current epilogue: the residual tensor, or (second K half) the first half's partial tile
+        auto res_on = [&]() __attribute__((always_inline)) -> bool { return RES || (MODE == 2 && ks == 2 && e_kh == 1); };
         auto res_batch = [&](int q, u32x4* dst) __attribute__((always_inline)) {
-            if constexpr (RES) {
-                unsigned eb = e_base; asm volatile("" : "+v"(eb));
+            if constexpr (RR) {
+                if (res_on()) {
+                    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)((ks == 2 && e_kh == 1) ? kpartb : (resb ? resb : outb)), 0, out_bytes, 0x00020000);
+                    unsigned eb = e_base; asm volatile("" : "+v"(eb));
+                    if (ks == 2 && e_kh == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, item_off(eb, q * 4 + i), 0, 0);
+                        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 1);   // sc0: bypass L1
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
+                    }
+                }
             }
         };
         // start of the epilogue iteration: bias / FiLM (raw: folding them here would wait for the loads) and the first two
         // residual batches; all of it flies during request()
         auto epi_request = [&]() __attribute__((always_inline)) {
+            if (ks == 2 && e_kh == 1) {
+                // second K half: the partner's partial tile must be complete.  Thread t reads exactly what thread t of the partner
+                // wrote, so one flag per producer wave is enough.  Bounded spin: a protocol bug must not hang the GPU.
+                unsigned* const fl = a.kflag + (size_t)e_tile * 4 + pw;
+                if (lane == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                    __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                }
+                // No agent-scope acquire fence here (it would invalidate the XCD's whole L2): the partner workgroup runs on the
+                // same XCD (adjacent virtual tiles, XCD-contiguous mapping above), its stores are write-through to that L2, and
+                // this CU cannot hold stale lines of the partial tensor (L1 is invalidated at kernel start and the lines are
+                // read for the first time now, with the L1-bypass bit set for good measure).
+                asm volatile("" ::: "memory");
+            }
             const int nb = e_nt * BN + o16 * 8;
             const int nbs = nb < a.Cout ? nb : 0;
             fb[0] = *(const f32x4*)(a.bias + nbs); fb[1] = *(const f32x4*)(a.bias + nbs + 4);
@@ -254,22 +297,26 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 }
             }
             res_batch(0, rr[0]);
-            if constexpr (RES) res_batch(1, rr[1]);
+            if constexpr (RR) res_batch(1, rr[1]);
         };
         // the staging tile of the tile described by e_* is complete (the consumers wrote it before the last barrier)
         auto epilogue = [&]() __attribute__((always_inline)) {
             // scalar fp32 math only (packed-fp32 ops starve next to the consumers' MFMA stream, see GnCoef), and the running
             // sums pinned per item: left alone the compiler sums ACROSS the 16 unrolled items at the end and keeps all 128
             // output values alive until then
+            const bool first = ks == 2 && e_kh == 0, second = ks == 2 && e_kh == 1;
+            // the first K half carries bias / FiLM shift / residual; the second only scales by the FiLM factor and adds the partial
             float f1[RES ? 1 : 8], f2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                f2[e] = fb[e >> 2][e & 3];
+                f2[e] = second ? 0.f : fb[e >> 2][e & 3];
                 if constexpr (!RES) {
                     f1[e] = 1.f;
-                    if (a.film) { f1[e] = 1.0f + fs[e >> 2][e & 3]; f2[e] = fmaf(f2[e], f1[e], ft[e >> 2][e & 3]); }
+                    if (a.film) { f1[e] = 1.0f + fs[e >> 2][e & 3]; f2[e] = second ? 0.f : fmaf(f2[e], f1[e], ft[e >> 2][e & 3]); }
                 }
             }
+            const auto osrd_c = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? kpartb : outb), 0, out_bytes, 0x00020000);
+            const bool radd = res_on();
             float s1[8], s2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -293,17 +340,32 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], f1[e], f2[e]);
+                        if constexpr (MODE == 2) {
+                            if (radd) {
+                                float rv[8];
+                                Vec16<T>::unpack(rr[q & 1][i], rv);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) x[e] += rv[e];
+                            }
+                        }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float u = x[e] * mk; s1[e] += u; s2[e] = fmaf(u, x[e], s2[e]); }
                     asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
                     asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (RES) { if (q + 2 < 4) res_batch(q + 2, rr[q & 1]); }   // refill the buffer just consumed, one batch ahead
+                if constexpr (RR) { if (q + 2 < 4) res_batch(q + 2, rr[q & 1]); }    // refill the buffer just consumed, one batch ahead
             }
-            if (a.part) {
+            if (first) {
+                // publish the partial tile: every store of this wave visible at agent scope, then its flag
+                // (stores are write-through to the XCD's L2; waiting for their acknowledgement is the release -- an agent-scope
+                // release fence would write back the whole L2)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(a.kflag + (size_t)e_tile * 4 + pw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (a.part && !first) {
 #pragma unroll
                 for (int s = 16; s < 64; s <<= 1)
 #pragma unroll
@@ -346,12 +408,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
             if (epi) epi_request();
             if (k + 1 < ktotal) issue();
-            if (c == a.nchunk - 1) epi_setup(vb + ti * grid);      // this tile finishes in this iteration
+            if (c == nck - 1) epi_setup(vb + ti * grid);           // this tile finishes in this iteration
             if (a.stamps) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
             if (epi) epilogue();
             if (a.stamps) t_b += __builtin_amdgcn_s_memtime() - t0;
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
-            if (++c == a.nchunk) { c = 0; ++ti; }
+            if (++c == nck) { c = 0; ++ti; }
         }
         epi_request();
         epilogue();                                                // last tile
@@ -379,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
     u32x4 bq[D][NF];
     {
-        const unsigned wb = wbase_of(vb, 0);
+        const unsigned wb = wbase_of(vt_tile(vb), vt_kh(vb) * nck);
 #pragma unroll
         for (int s = 0; s < D - 1; ++s)
 #pragma unroll
@@ -392,8 +454,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     stamp(1);
     int k = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        const int tile = vb + ti * grid;
-        const int tile_next = tile + grid < ntiles ? tile + grid : tile;
+        const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
+        const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
         int toffs[NTAPS == 9 ? 1 : NTAPS];                         // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
             const int par = (tile / a.n_nt) % a.npar;
@@ -406,12 +468,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-        for (int chunk = 0; chunk < a.nchunk; ++chunk, ++k) {
-            const unsigned wb_cur = wbase_of(tile, chunk);
-            const unsigned wb_nxt = chunk + 1 < a.nchunk ? wbase_of(tile, chunk + 1) : wbase_of(tile_next, 0);
+        for (int chunk = 0; chunk < nck; ++chunk, ++k) {
+            const unsigned wb_cur = wbase_of(tile, c0 + chunk);
+            const unsigned wb_nxt = chunk + 1 < nck ? wbase_of(tile, c0 + chunk + 1) : wbase_of(vt_tile(v_next), vt_kh(v_next) * nck);
             const int bufoff = (k & 1) * L::A_BYTES;
             if constexpr (S2) {                                    // this pass's two taps inside the staged plane (table in the header)
-                const int pass = chunk % 5;
+                const int pass = (c0 + chunk) % 5;
                 toffs[0] = (pass == 0 || pass == 2) ? -HPITCH - (pass == 0 ? 1 : 0) : ((pass == 1 || pass == 3) ? -1 : 0);
                 toffs[1] = pass == 0 ? -HPITCH : 0;
             }
@@ -460,7 +522,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 __builtin_amdgcn_sched_barrier(0);
             }
             }
-            if (chunk + 1 == a.nchunk) {
+            if (chunk + 1 == nck) {
                 // hand the tile to the producers: bf16 staging, 8 bytes (4 channels) per store
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
@@ -486,11 +548,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #define PR_D 9
 #endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
-static pr_fn_t pick_pr(int ntaps, bool res)
+static pr_fn_t pick_pr(int ntaps, int mode)
 {
-    if (ntaps == 9) return res ? (pr_fn_t)conv_pr_kernel<9, PR_D, true> : (pr_fn_t)conv_pr_kernel<9, PR_D, false>;
-    if (ntaps == 2) return res ? (pr_fn_t)conv_pr_kernel<2, 8, true> : (pr_fn_t)conv_pr_kernel<2, 8, false>;
-    return res ? (pr_fn_t)conv_pr_kernel<4, 8, true> : (pr_fn_t)conv_pr_kernel<4, 8, false>;
+    if (ntaps == 9) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0>);
+    if (ntaps == 2) return mode == 1 ? (pr_fn_t)conv_pr_kernel<2, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<2, 8, 2> : (pr_fn_t)conv_pr_kernel<2, 8, 0>);
+    return mode == 1 ? (pr_fn_t)conv_pr_kernel<4, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<4, 8, 2> : (pr_fn_t)conv_pr_kernel<4, 8, 0>);
 }
 
 bool conv_pr_supported(int kind, int bn, int th) { return (kind == KIND_C3S1 || kind == KIND_CT4 || kind == KIND_C3S2) && bn == 128 && th == 8; }
@@ -500,8 +562,8 @@ hipError_t conv_pr_prepare()
 {
     hipError_t e = hipSuccess;
     for (int ntaps : {2, 4, 9})
-        for (int res = 0; res < 2; ++res) {
-            e = hipFuncSetAttribute((const void*)pick_pr(ntaps, res != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
+        for (int mode = 0; mode < 3; ++mode) {
+            e = hipFuncSetAttribute((const void*)pick_pr(ntaps, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
             if (e != hipSuccess) return e;
         }
     int dev = 0;
@@ -535,10 +597,13 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
     const bool s2 = a.ntaps == 2 && a.npar == 1 && a.OS == 1 && !a.gn_ab && (a.nchunk % 5) == 0;
     if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || a.th != 8 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
-    const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt;
+    const int ks = a.ksplit == 2 ? 2 : 1;
+    if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5))) return hipErrorInvalidValue;
+    const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt * ks;
     static const int cap = getenv("CCN_PR_GRID") ? atoi(getenv("CCN_PR_GRID")) : 0;
     int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);
     if (grid > ntiles) grid = ntiles;
+    if (ks == 2) grid &= ~1;                                     // partners (2*tile, 2*tile+1) run in adjacent workgroups at the same time
     ConvArgs d = a;
     static const char* env = getenv("CCN_STAMPS");
     if (env && (unsigned)atoi(env) == (unsigned)ntiles) {
@@ -546,7 +611,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
         g_stamp_grid = (unsigned)grid;
         d.stamps = g_stamps;
     } else d.stamps = nullptr;
-    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res != nullptr), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
+    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res ? 1 : (ks == 2 ? 2 : 0)), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
     return hipGetLastError();
 }
 
