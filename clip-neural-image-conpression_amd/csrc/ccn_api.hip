@@ -298,15 +298,17 @@ int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2
         const size_t n = (size_t)nch * n32 * 9 * 4 * 64 * epc;
         std::vector<float> tmp(n, 0.f);
         size_t p = 0;
+        // step j of a chunk = (dx = j/12, k-slice kk = (j/3)%4, dy = j%3): the kernel walks the taps column by column so that one
+        // LDS address serves the three dy taps (ccn_conv_pr.hip)
         for (int c = 0; c < nch; ++c)
             for (int nn = 0; nn < n32; ++nn)
-                for (int t = 0; t < 9; ++t)
-                    for (int kk = 0; kk < 4; ++kk)
-                        for (int ln = 0; ln < 64; ++ln)
-                            for (int e = 0; e < epc; ++e, ++p) {
-                                const int o = nn * 32 + (ln & 31), i = c * cke + (2 * kk + (ln >> 5)) * epc + e;
-                                tmp[p] = (o < O && i < I) ? w[((size_t)o * I + i) * 9 + t] : 0.f;
-                            }
+                for (int j = 0; j < 36; ++j)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < epc; ++e, ++p) {
+                            const int dx = j / 12, kk = (j / 3) % 4, dy = j % 3, t = dy * 3 + dx;
+                            const int o = nn * 32 + (ln & 31), i = c * cke + (2 * kk + (ln >> 5)) * epc + e;
+                            tmp[p] = (o < O && i < I) ? w[((size_t)o * I + i) * 9 + t] : 0.f;
+                        }
         if (h->cfg.dtype == CCN_DTYPE_BF16) {
             std::vector<uint16_t> b16(n);
             for (size_t q = 0; q < n; ++q) b16[q] = f2bf_host(tmp[q]);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto stamp_cycles = [&]() __attribute__((always_inline)) {
         if (a.stamps && lane == 0 && (wave == 0 || wave == 4)) {
             unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8;
-            st[3] = t_bar; st[4] = __builtin_amdgcn_s_memtime() - t_begin; st[5] = t_a; st[6] = t_b; st[7] = t_w; st[1] = t_r;
+            st[3] = t_bar; st[4] = __builtin_amdgcn_s_memtime() - t_begin; st[5] = t_a; st[6] = t_b; st[7] = t_r;
         }
     };
     stamp(0);
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         auto dump = [&](int buf) __attribute__((always_inline)) {
             unsigned char* const As = smem + buf * L::A_BYTES;
             int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
-            const int swz0 = pc >> 1;
+            // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
+            // fragment address by a constant, which lets the consumers address all three dy taps with immediate offsets
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 u32x4 v = areg[i];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     v = u32x4{ok ? tr[0] : 0u, ok ? tr[1] : 0u, ok ? tr[2] : 0u, ok ? tr[3] : 0u};   // padding stays zero
                 }
                 const int px = i < 10 ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
-                const int sw = i < 10 ? (swz0 + i) : (px >> 1);              // (px >> 1) & 7 == (i*17 + (pcol>>1)) & 7
+                const int sw = i < 10 ? (pc >> 1) : 0;                       // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
                 if (i < 10 || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
                 if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
             }
@@ -425,10 +426,16 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[MF][NF];
-    auto rbase = [&](int row) __attribute__((always_inline)) { return row * 128 + ((((row >> 1) & 6)) << 4) + (((h ^ (row >> 1)) & 1) << 4); };
+    // byte offset of this lane's 16-byte slice (k-slice 0) of halo pixel (row_lin = hy*HPITCH + hx): slice index h ^ (hx >> 1)
+    // in the low bit and (hx >> 1) & 6 above it; k-slice kk flips bits 5-6 of the address (XOR with kk << 5)
+    auto rbase = [&](int row_lin, int hx) __attribute__((always_inline)) { return row_lin * 128 + (((hx >> 1) & 6) << 4) + (((h ^ (hx >> 1)) & 1) << 4); };
     int prow[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) prow[i] = ((wm * MF + i) + 1) * HPITCH + r + 1;
+    // 3x3: per dx the swizzle term of column r + 1 + dx plus the dx pixel step, relative to the (dy = -1) row
+    int b16x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b16x[d] = rbase(d - 1 - HPITCH, r + d);
     // weight fragments: [chunk][Cout_pad/32][tap][kk][lane] x 16 B (host-packed); this wave owns columns nt*4 + wn*2 + {0,1}
     const int n32 = a.Cout_pad / 32;
     constexpr unsigned COLB = NSTEP * 1024;                        // bytes of one 32-channel column of one chunk
@@ -456,11 +463,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
-        int toffs[NTAPS == 9 ? 1 : NTAPS];                         // ConvTranspose: the parity's 2x2 taps (wave-uniform)
+        int toffs[NTAPS == 9 ? 1 : NTAPS], tdxs[NTAPS == 9 ? 1 : NTAPS];   // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
             const int par = (tile / a.n_nt) % a.npar;
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + a.tapinfo_dx(par * 4 + t);
+            for (int t = 0; t < NTAPS; ++t) { tdxs[t] = a.tapinfo_dx(par * 4 + t); toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + tdxs[t]; }
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -474,22 +481,39 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int bufoff = (k & 1) * L::A_BYTES;
             if constexpr (S2) {                                    // this pass's two taps inside the staged plane (table in the header)
                 const int pass = (c0 + chunk) % 5;
-                toffs[0] = (pass == 0 || pass == 2) ? -HPITCH - (pass == 0 ? 1 : 0) : ((pass == 1 || pass == 3) ? -1 : 0);
+                tdxs[0] = (pass == 0 || pass == 1 || pass == 3) ? -1 : 0; tdxs[1] = 0;
+                toffs[0] = ((pass == 0 || pass == 2) ? -HPITCH : 0) + tdxs[0];
                 toffs[1] = pass == 0 ? -HPITCH : 0;
             }
 #pragma unroll
             for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop
             u32x4 av[2][MF];
-            int abase[MF];
+            int abase[MF], akk[MF];
+            // 3x3: steps run in (dx, kk, dy) order -- the address of (row i, dx, kk) serves the three dy taps through the
+            // ds_read immediate offset (dy * HPITCH * 128): 48 address VALU ops per chunk instead of 430, on a SIMD whose VALU
+            // issue is shared with a producer wave.  Other tap sets: (tap, kk) order, one address set per tap.
             auto frag = [&](int j, u32x4* av_) __attribute__((always_inline)) {
-                const int tt = j >> 2, kk = j & 3;
-                if (kk == 0) {
-                    const int toff = NTAPS == 9 ? (tt / 3 - 1) * HPITCH + (tt % 3 - 1) : toffs[NTAPS == 9 ? 0 : tt];
+                if constexpr (NTAPS == 9) {
+                    const int dxi = j / 12, kk = (j / 3) & 3, dyi = j % 3;
+                    if (j % 12 == 0) {
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toff);
+                        for (int i = 0; i < MF; ++i) abase[i] = bufoff + prow[i] * 128 + b16x[dxi];
+                    }
+                    if (j % 3 == 0) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i) akk[i] = abase[i] ^ (kk << 5);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + akk[i] + dyi * HPITCH * 128);
+                } else {
+                    const int tt = j >> 2, kk = j & 3;
+                    if (kk == 0) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toffs[NTAPS == 9 ? 0 : tt], r + 1 + tdxs[NTAPS == 9 ? 0 : tt]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
                 }
-#pragma unroll
-                for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
             };
             if (!(a.dbg & 64)) {                                   // CCN_DBG=64: consumers idle (timing experiments only)
             frag(0, av[0]);
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
 #ifndef PR_D
-#define PR_D 9
+#define PR_D 6
 #endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
 static pr_fn_t pick_pr(int ntaps, int mode)
