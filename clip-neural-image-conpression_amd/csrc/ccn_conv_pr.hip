@@ -56,6 +56,7 @@ static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 template <int NTAPS, int D, int MODE>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
+    constexpr bool COLW = true;                                // 3x3: column-per-wave consumers (false: the 4x2 fragment form)
     constexpr bool RES = MODE == 1;                            // residual registers: MODE 1 always, MODE 2 in the second K half
     constexpr bool RR = MODE != 0;
     typedef __bf16 T;
@@ -424,6 +425,111 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 
     // ---------------------------------------------------------------------- consumers (4 waves)
     if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
+    if constexpr (NTAPS == 9 && COLW) {
+        // 3x3, column-per-wave form: wave w owns ALL 8 tile rows of the 32 output channels nt*128 + 32w.  Per (dx, k-slice)
+        // group it needs 3 weight fragments (one per dy) -- half the L1 traffic of the 4x2 form, whose row pairs fetched the
+        // same weights twice -- and the 10 halo rows of that column/slice, each read ONCE from LDS and used for up to three
+        // (output row, dy) pairs the moment it arrives (row hh feeds output rows hh, hh-1, hh-2), so only the prefetch window is live.
+        constexpr int WIN = 6, PF = 4;                             // row-fragment window / prefetch distance (rows)
+        constexpr int DG = 3;                                      // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
+        constexpr int NG = 12, NROW = 10;
+        static_assert((NG * NROW) % WIN == 0 && NG % DG == 0, "static ring indexing");
+        f32x16 acc[8];
+        const int n32 = a.Cout_pad / 32;
+        constexpr unsigned COLB = 36 * 1024;
+        const unsigned wtotal = (unsigned)((size_t)a.nchunk * n32 * COLB);
+        const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
+        const unsigned lane16 = (unsigned)lane * 16u;
+        auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
+            const int nt = tile % a.n_nt;
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(chunk * n32 + nt * 4 + wave) * COLB));
+        };
+        auto rbase = [&](int row_lin, int hx) __attribute__((always_inline)) { return row_lin * 128 + (((hx >> 1) & 6) << 4) + (((h ^ (hx >> 1)) & 1) << 4); };
+        int b16x[3];                                               // halo row 0, column r + dx (dx = 0..2 <-> -1..+1), k-slice 0
+#pragma unroll
+        for (int d = 0; d < 3; ++d) b16x[d] = rbase(r + d, r + d);
+        u32x4 bq[DG][3];
+        {
+            const unsigned wb = wbase_of(vt_tile(vb), vt_kh(vb) * nck);
+#pragma unroll
+            for (int g = 0; g < DG - 1; ++g)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) bq[g][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, wb + (g * 3 + dy) * 1024, 0);
+        }
+        // staging address of this lane: pixel i*32 + r, channels 32*wave + g*8 + 4*h .. +3
+        const int stg_lane = r * L::SP + (wave * 32 + 4 * h) * 2;
+        raw_barrier();                                             // chunk 0 visible
+        stamp(1);
+        int k = 0;
+        for (int ti = 0; ti < my_tiles; ++ti) {
+            const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
+            const int tile = vt_tile(v), c0 = vt_kh(v) * nck;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
+            for (int chunk = 0; chunk < nck; ++chunk, ++k) {
+                const unsigned wb_cur = wbase_of(tile, c0 + chunk);
+                const unsigned wb_nxt = chunk + 1 < nck ? wbase_of(tile, c0 + chunk + 1) : wbase_of(vt_tile(v_next), vt_kh(v_next) * nck);
+                int bufoff = (k & 1) * L::A_BYTES; asm volatile("" : "+v"(bufoff));
+                u32x4 rw[WIN];
+                int ag = 0;
+                // row fragment `s` of the chunk's stream (group s / 10, halo row s % 10)
+                auto rload = [&](int s_) __attribute__((always_inline)) {
+                    const int g = s_ / NROW, hh = s_ % NROW;
+                    if (hh == 0) ag = (bufoff + b16x[g / 4]) ^ ((g & 3) << 5);
+                    rw[s_ % WIN] = *(const u32x4*)(smem + ag + hh * HPITCH * 128);
+                };
+                if (!(a.dbg & 64)) {
+#pragma unroll
+                for (int s_ = 0; s_ < PF; ++s_) rload(s_);
+#pragma unroll
+                for (int s_ = 0; s_ < NG * NROW; ++s_) {
+                    const int g = s_ / NROW, hh = s_ % NROW;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (hh == 0) {
+                        // refill the ring slot group g-1 released with the fragments of group g+DG-1 (wraps into the next chunk / tile)
+                        const int pg = g + DG - 1;
+                        const unsigned off = pg < NG ? wb_cur + (unsigned)(pg * 3) * 1024u : wb_nxt + (unsigned)((pg - NG) * 3) * 1024u;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) bq[pg % DG][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off + dy * 1024, 0);
+                    }
+                    if (s_ + PF < NG * NROW) rload(s_ + PF);
+                    int nm = 0;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int i = hh - dy;
+                        if (i >= 0 && i < 8) { mfma16<T>(acc[i], bq[g % DG][dy], rw[s_ % WIN]); ++nm; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (hh == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                }
+                if (chunk + 1 == nck) {
+                    // hand the tile to the producers: bf16 staging, 8 bytes (4 channels) per store
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& c = acc[i];
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 pk = {pack_bf2(c[g * 4], c[g * 4 + 1]), pack_bf2(c[g * 4 + 2], c[g * 4 + 3])};
+                            *(u32x2*)(stg + stg_lane + i * 32 * L::SP + (g * 8) * 2) = pk;
+                        }
+                }
+                timed_barrier();                                   // chunk k+1 visible, chunk k released, staging complete
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        stamp(2); stamp_cycles();
+        return;
+    }
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[MF][NF];
     // byte offset of this lane's 16-byte slice (k-slice 0) of halo pixel (row_lin = hy*HPITCH + hx): slice index h ^ (hx >> 1)
@@ -630,7 +736,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     if (ks == 2) grid &= ~1;                                     // partners (2*tile, 2*tile+1) run in adjacent workgroups at the same time
     ConvArgs d = a;
     static const char* env = getenv("CCN_STAMPS");
-    if (env && (unsigned)atoi(env) == (unsigned)ntiles) {
+    if (env && (unsigned)atoi(env) == (unsigned)ntiles && (!strchr(env, ':') || atoi(strchr(env, ':') + 1) == a.ntaps)) {   // CCN_STAMPS=<tiles>[:<ntaps>]
         if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
         g_stamp_grid = (unsigned)grid;
         d.stamps = g_stamps;
