@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a)
         };
         auto a_req = [&](int chunk, int i) __attribute__((always_inline)) {          // zeros if the chunk / slice / pixel does not exist
             const bool cv = chunk < a.nchunk && chunk * CKE + ck * EPC < a.Cin;
-            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_srd(cv ? chunk : 0), cv ? a_off(i) : OOB, 0, 0);
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_srd(chunk < a.nchunk ? chunk : 0), cv ? a_off(i) : OOB, 0, 0);
         };
         // vmcnt retires in order: coefficient loads are always issued BEFORE the input requests of the same stage, so
         // waiting for them never waits for HBM

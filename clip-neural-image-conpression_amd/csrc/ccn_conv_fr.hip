@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
             const int cb = chunk * CKE + ck * EPC;
             const bool cv = chunk < a.nchunk && cb < a.Cin;
             gk.load(a.gn_ab + (size_t)b * a.Cin + (cv ? cb : 0), gn && cv);     // first: its wait must not wait for the HBM requests below
-            const auto srd = in_srd(cv ? chunk : 0);
+            const auto srd = in_srd(chunk < a.nchunk ? chunk : 0);
 #pragma unroll
             for (int i = 0; i < AIT; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, cv ? a_off(i) : OOB, 0, 0);
         };

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int cb = cc * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gk = gkn;
-            const unsigned coff = (unsigned)((size_t)(cv ? cc : 0) * CKE * sizeof(T));
+            // the descriptor must be WAVE-UNIFORM (cv is per lane: a lane-dependent base makes the compiler wrap every load in a
+            // readfirstlane waterfall loop -- 1.6 us per request); per-lane validity goes into the offset masks instead
+            const unsigned coff = (unsigned)((size_t)((q_tv && cc * CKE < a.Cin) ? cc : 0) * CKE * sizeof(T));
             const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + coff), 0, in_bytes - coff, 0x00020000);
             const int rs = IS * a.Win * a.Cin * (int)sizeof(T);                   // row stride of the staged plane in bytes
             const int ixr = IS * (ix0 + pcol) + px;                               // input column of this thread's halo column

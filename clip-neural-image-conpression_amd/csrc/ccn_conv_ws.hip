@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
 #pragma unroll
         for (int u = 0; u < BU0; ++u) {
             const int idx = tid + 512 * u, tt = idx / (BN * 8), rem = idx - tt * (BN * 8), n = rem >> 3, ckb = rem & 7;
-            b0[u] = __builtin_amdgcn_raw_buffer_load_b128(w_srd(tt, 0), (unsigned)(((size_t)(n0 + n) * a.Cin_pad) * sizeof(T) + ckb * 16), 0, 0);
+            b0[u] = __builtin_amdgcn_raw_buffer_load_b128(w_srd(__builtin_amdgcn_readfirstlane(tt), 0), (unsigned)(((size_t)(n0 + n) * a.Cin_pad) * sizeof(T) + ckb * 16), 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < PIT; ++i) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
         };
         auto a_req = [&](int chunk, int i) __attribute__((always_inline)) {          // zeros if the chunk / slice / pixel does not exist
             const bool cv = chunk < a.nchunk && chunk * CKE + ck * EPC < a.Cin;
-            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_srd(cv ? chunk : 0), cv ? a_off(i) : OOB, 0, 0);
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_srd(chunk < a.nchunk ? chunk : 0), cv ? a_off(i) : OOB, 0, 0);
         };
         // vmcnt retires in order: coefficient loads are always issued BEFORE the input requests of the same stage, so
         // waiting for them never waits for HBM
