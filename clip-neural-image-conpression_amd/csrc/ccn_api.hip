@@ -152,6 +152,7 @@ struct ccn_handle_s {
     std::vector<Layer> layers;
     float *tp0_w = nullptr, *tp0_b = nullptr, *tp2_w = nullptr, *tp2_b = nullptr, *zp_w = nullptr, *zp_b = nullptr;
     float *film_w = nullptr, *film_b = nullptr;
+    float* head_w_f32 = nullptr;       // (img_ch, C, 3, 3) fp32 copy of out.weight for the dedicated head kernel
     int F = 0;                          // rows of the concatenated FiLM linear
     int G = 8;
     std::vector<std::unique_ptr<Plan>> plans;
@@ -605,7 +606,7 @@ struct PlanBuilder {
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
                          (preact_pr || r.c1.Cout_pad / r.c1.BN >= 4 || !will_use_pr(r.c1, x.H, x.W));
         static const bool fuse_act = !getenv("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
-        const bool f1 = pre && fuse_act && x.part, f2 = pre && fuse_act;
+        const bool f1 = pre && fuse_act && x.n_sp > 0, f2 = pre && fuse_act;     // (n_sp, not the pointer: null while measuring)
         TensorRef y = new_tensor(r.C, x.H, x.W);
         if (f1) { TensorRef xa = preact_fused(x, r.n1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
         else {
@@ -683,6 +684,27 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
                 break;
             }
             case L_HEAD: {
+                static const bool no_head2 = getenv("CCN_NO_HEAD2") != nullptr;
+                if (!no_head2 && head2_supported(c.dtype, h->head.Cin, h->head.Cout, h->G)) {
+                    // dedicated kernel pair: out_norm's finalize folded into per-sample head weights, taps in the N dimension
+                    std::shared_ptr<ConvArgs> ap(new ConvArgs());
+                    ConvArgs& a = *ap;
+                    a.in = x.p; a.bias = h->head.bias; a.B = B; a.Hin = H; a.Win = W; a.Cin = h->head.Cin; a.Cout = h->head.Cout;
+                    a.Hout = H; a.Wout = W;
+                    const float2* ab = pb.gn(x, h->out_norm);
+                    void* scratch = pb.bump.take(head2_scratch_bytes(B, x.C));
+                    const float* wf = h->head_w_f32;
+                    const double macs = (double)B * H * W * h->head.Cout * 9.0 * h->head.Cin;
+                    Launch Lh{F_HEAD, 2.0 * macs, ((double)B * H * W * x.C + 9.0 * x.C * h->head.Cout) * h->elem + 3.0 * (double)B * H * W * h->head.Cout * 4, nullptr};
+                    Lh.fn = [=](hipStream_t s, const StepCtx& sc) -> hipError_t {
+                        ConvArgs k = *ap;
+                        k.x_state = sc.x_state; k.eps_out = sc.eps_out; k.do_ddim = sc.do_ddim;
+                        k.c0 = sc.c[0]; k.c1 = sc.c[1]; k.c2 = sc.c[2]; k.c3 = sc.c[3];
+                        return launch_head2(k, ab, wf, scratch, s);
+                    };
+                    plan->ops.push_back(std::move(Lh));
+                    break;
+                }
                 const float2* ab = pb.gn(x, h->out_norm);
                 TensorRef none;
                 pb.conv(h->head, F_HEAD, x, none, ab, -1, nullptr, false, false, true);
@@ -909,6 +931,7 @@ int ccn_commit_params(ccn_handle_t h)
         if ((rc = pack_convT(h, h->ups[i], "up." + std::to_string(3 * i + 2)))) return rc;
     h->head = ConvW(); h->head.kind = KIND_HEAD; h->head.Cin = c.base; h->head.Cout = c.img_ch;
     if ((rc = pack_conv3(h, h->head, "out"))) return rc;
+    if ((rc = upload_f32(h, "out.weight", &h->head_w_f32))) return rc;
     h->out_norm.C = c.base;
     if ((rc = upload_f32(h, "out_norm.weight", &h->out_norm.gamma))) return rc;
     if ((rc = upload_f32(h, "out_norm.bias", &h->out_norm.beta))) return rc;
