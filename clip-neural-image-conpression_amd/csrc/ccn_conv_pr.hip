@@ -148,49 +148,52 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         bool q_tv = false;
         auto prep = [&]() __attribute__((always_inline)) {
             const int v = vb + rq_ti * grid;
-            q_tv = v < ntiles;
-            const int tile = vt_tile(q_tv ? v : vb);
-            const int sp = tile / (a.n_nt * a.npar);                       // tile = ((spatial tile) * npar + parity) * n_nt + N tile
-            const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
-            q_b = sp / (a.n_tx * a.n_ty);
-            q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1; q_c = vt_kh(v) * nck + rq_c;
+            if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
+                q_tv = v < ntiles;
+                const int tile = vt_tile(q_tv ? v : vb);
+                const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+                const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
+                q_b = sp / (a.n_tx * a.n_ty);
+                q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
+            }
+            q_c = vt_kh(v) * nck + rq_c;
             const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gkn.load(a.gn_ab + (size_t)q_b * a.Cin + (cv ? cb : 0), gn && cv);
             if (++rq_c == nck) { rq_c = 0; ++rq_ti; }
         };
         auto issue = [&]() __attribute__((always_inline)) {
-            const int b = q_b, iy0 = q_iy0, ix0 = q_ix0;
-            const int cc = S2 ? q_c / 5 : q_c;                                     // channel chunk
+            // (readfirstlane: these are wave-uniform by construction; saying so keeps the descriptor in SGPRs)
+            const int b = __builtin_amdgcn_readfirstlane(q_b), iy0 = __builtin_amdgcn_readfirstlane(q_iy0), ix0 = __builtin_amdgcn_readfirstlane(q_ix0);
+            const int cc = __builtin_amdgcn_readfirstlane(S2 ? q_c / 5 : q_c);     // channel chunk
             const int pass = S2 ? q_c - cc * 5 : 0;
             const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
             const int cb = cc * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             gk = gkn;
-            // the descriptor must be WAVE-UNIFORM (cv is per lane: a lane-dependent base makes the compiler wrap every load in a
-            // readfirstlane waterfall loop -- 1.6 us per request); per-lane validity goes into the offset masks instead
-            const unsigned coff = (unsigned)((size_t)((q_tv && cc * CKE < a.Cin) ? cc : 0) * CKE * sizeof(T));
-            const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + coff), 0, in_bytes - coff, 0x00020000);
+            // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
+            // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
+            // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
+            // per-row compare; only the column validity (and the channel tail) is per lane, ORed in as an out-of-range constant.
+            const unsigned img_bytes = (unsigned)(a.Hin * a.Win * a.Cin) * (unsigned)sizeof(T);
+            const unsigned coff = (unsigned)(((q_tv && cc * CKE < a.Cin) ? cc : 0) * CKE) * (unsigned)sizeof(T);
+            const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + (size_t)b * img_bytes + coff), 0, img_bytes - coff, 0x00020000);
             const int rs = IS * a.Win * a.Cin * (int)sizeof(T);                   // row stride of the staged plane in bytes
             const int ixr = IS * (ix0 + pcol) + px;                               // input column of this thread's halo column
             colv = cv && ixr >= 0 && ixr < a.Win;
-            // branch-free validity: OR an out-of-range constant into the offset (an invalid row or column may have produced
-            // any value, negative included -- all of them stay past num_records once the mask is ORed in)
             const unsigned cmask = colv ? 0u : OOB;
-            const int base = ((b * a.Hin + IS * iy0 + py) * a.Win + ixr) * a.Cin * (int)sizeof(T) + ck * 16;
-            rowm = 0;
+            const int base = ((IS * iy0 + py) * a.Win + ixr) * a.Cin * (int)sizeof(T) + ck * 16;
+            // halo rows inside the image: [r_lo, r_hi) (wave-uniform), as a bit mask for the padding-stays-zero select in dump()
+            const int first = IS * iy0 + py;                                      // input row of halo row 0
+            const int r_lo = first < 0 ? (-first + IS - 1) / IS : 0;
+            int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > 10 ? 10 : (r_hi < 0 ? 0 : r_hi);
+            rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int iyr = IS * (iy0 + i) + py;
-                const bool rv = iyr >= 0 && iyr < a.Hin;                          // wave-uniform
-                const unsigned rmask = rv ? 0u : OOB;
-                rowm |= rv ? (1u << i) : 0u;
-                areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask | rmask, 0, 0);
-            }
+            for (int i = 0; i < 10; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
             {
                 const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
                 xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
-                const int off = ((b * a.Hin + iyr) * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
+                const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
                 areg[10] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
             }
         };
