@@ -1,6 +1,6 @@
 // "Free-running" warp-specialised implicit-GEMM convolution: no workgroup barrier inside a Cin chunk.
 //
-// Measurements on the barrier-per-stage kernels (ccn_conv_ws.hip / ccn_conv_dma.hip) showed the consumer waves are the
+// Measurements on the barrier-per-stage kernels (ccn_conv_ws.hip and a shared LDS-DMA-ring variant of it) showed the consumer waves are the
 // pole: they hardly wait at the barriers, but every stage restarts their LDS-read -> MFMA pipeline behind a barrier
 // and the loop runs at ~50 % of the MFMA rate.  Here the consumers never synchronise with anybody inside a chunk:
 //   * weights (B): every consumer wave owns a PRIVATE ring of three one-tap slots for the 32*NF output channels it
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
     constexpr int HPITCH = G::HPITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const As = smem;
-    unsigned char* const Bs = smem + L::A_BYTES;            // [wave 0..3][NBUF][32*NF rows of 128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
             int chunk = tg / NTAPS, tap = tg - chunk * NTAPS;
             if (chunk >= a.nchunk) { chunk = a.nchunk - 1; }                  // past the end: harmless re-read, keeps vmcnt uniform
             const auto srd = w_srd(tap, chunk);
-            const int slot = tg % NBUF;
+            [[maybe_unused]] const int slot = tg % NBUF;             // (used by the device pass only)
 #pragma unroll
             for (int k = 0; k < PP; ++k) {
                 const int row = 8 * k + (lane >> 3);                           // row inside the private tile

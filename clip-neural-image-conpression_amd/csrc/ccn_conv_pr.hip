@@ -33,7 +33,6 @@ namespace {
 struct PrLds {
     static constexpr int HROWS = 10, HPITCH = 34;
     static constexpr int A_BYTES = HROWS * HPITCH * 128;       // one Cin chunk of the halo tile (43520)
-    static constexpr int AU = HROWS * HPITCH;                   // halo pixels
     static constexpr int SP = 272;                              // staging pitch in bytes: 128 bf16 channels + 16
     static constexpr int STG_BYTES = 256 * SP;                  // 256 pixels
     static constexpr int CHS_BYTES = 4 * 128 * 2 * 4;           // per producer wave: per-channel (sum, sum of squares)
@@ -98,7 +97,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const unsigned char* const inb = (const unsigned char*)a.in;
     const bool gn = a.gn_ab != nullptr && !(a.dbg & 32);     // CCN_DBG=32: skip the transform (timing experiments only)
     constexpr unsigned OOB = 0x7FFFFFF0u;
-    const unsigned in_bytes = (unsigned)((size_t)a.B * a.Hin * a.Win * a.Cin * sizeof(T));
     auto raw_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -224,8 +222,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         unsigned char* const outb = (unsigned char*)a.out;
         const unsigned char* const resb = (const unsigned char*)a.res;
         const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
-        const auto osrd = __builtin_amdgcn_make_buffer_rsrc((void*)outb, 0, out_bytes, 0x00020000);
-        const auto rsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(resb ? resb : outb), 0, out_bytes, 0x00020000);
         float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
         u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
         f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet

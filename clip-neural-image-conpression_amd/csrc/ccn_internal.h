@@ -71,10 +71,6 @@ bool conv_ws_enabled();
 bool conv_ws_supported(int kind, int bn);
 hipError_t conv_ws_prepare();
 hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s);
-// LDS-DMA variant (ccn_conv_dma.hip): weights by buffer_load...lds into a 3-stage ring, issued by the consumer waves
-bool conv_dma_enabled();
-hipError_t conv_dma_prepare();
-hipError_t launch_conv_dma(int dtype, int bn, const ConvArgs& a, hipStream_t s);
 // free-running variant (ccn_conv_fr.hip): private per-wave weight rings by LDS-DMA, no barrier inside a Cin chunk
 hipError_t conv_fr_prepare();
 hipError_t launch_conv_fr(int dtype, int bn, const ConvArgs& a, hipStream_t s);

@@ -403,15 +403,8 @@ hipError_t conv_prepare()
             }
     hipError_t e;
     if ((e = conv_ws_prepare()) != hipSuccess) return e;
-    if ((e = conv_dma_prepare()) != hipSuccess) return e;
     if ((e = conv_fr_prepare()) != hipSuccess) return e;
     return conv_pr_prepare();
-}
-
-bool conv_dma_enabled()
-{
-    static const int on = getenv("CCN_CONV_DMA") ? atoi(getenv("CCN_CONV_DMA")) : 0;
-    return on != 0;
 }
 
 bool conv_ws_enabled()
@@ -430,7 +423,7 @@ int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt)
     return blocks8 >= min8 ? 8 : 4;
 }
 
-// 0 ws everywhere, 1 shared LDS-DMA ring, 2 free-running everywhere, 3 free-running on 8-row tiles, 4 (default) persistent
+// 0 (or 1) ws everywhere, 2 free-running everywhere, 3 free-running on 8-row tiles, 4 (default) persistent
 // register-weight kernel where it applies, else as 3.  CCN_CONV_DMA overrides; tests switch it between handles.
 static int g_conv_variant = -1;
 static int conv_variant()
@@ -452,14 +445,12 @@ hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream
     if (conv_ws_enabled() && conv_ws_supported(kind, bn)) {
         static const int dbg = getenv("CCN_DBG") ? atoi(getenv("CCN_DBG")) : 0;
         ConvArgs d = a; d.dbg = dbg;
-        // 4 (default): persistent register-weight kernel on 8-row 3x3 tiles with 128-wide N tiles, else as 3
-        if (a.use_pr) return launch_conv_pr(dtype, d, s);
-        // 0 ws everywhere, 1 shared LDS-DMA ring, 2 free-running everywhere, 3 (default) free-running on 8-row tiles only:
-        // on 4-row tiles a consumer wave would issue 8 DMA pieces per 16 MFMAs and the private weight copies double the
-        // L2 traffic of the already weight-heavy 128-pixel tile
+        if (a.use_pr) return launch_conv_pr(dtype, d, s);        // decided at plan time (variant 4, bf16, 8-row tiles)
+        // free-running kernel on 8-row tiles only: on 4-row tiles a consumer wave would issue 8 DMA pieces per 16 MFMAs and
+        // the private weight copies double the L2 traffic of the already weight-heavy 128-pixel tile
         const int variant = conv_variant();
         if (variant == 2 || (variant >= 3 && a.th == 8)) return launch_conv_fr(dtype, bn, d, s);
-        return variant == 1 ? launch_conv_dma(dtype, bn, d, s) : launch_conv_ws(dtype, bn, d, s);
+        return launch_conv_ws(dtype, bn, d, s);
     }
     if (a.th != 4) return hipErrorInvalidValue;
     const conv_fn_t fn = pick(dtype, kind, bn);

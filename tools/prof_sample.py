@@ -29,6 +29,6 @@ import os, ctypes
 if os.environ.get("CCN_STAMPS"):
     from clip_feature_codec import _native
     lib = _native.load_library()
-    fn = {"1": lib.ccn_internal_dump_stamps_dma, "2": lib.ccn_internal_dump_stamps_fr, "3": lib.ccn_internal_dump_stamps_fr,
+    fn = {"2": lib.ccn_internal_dump_stamps_fr, "3": lib.ccn_internal_dump_stamps_fr,
           "4": lib.ccn_internal_dump_stamps_pr}.get(os.environ.get("CCN_CONV_DMA", "4"), lib.ccn_internal_dump_stamps)
     print("stamps dump rc", fn(b"gpurun_out/stamps.txt"))
