@@ -33,7 +33,17 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, c
         for (int i = 0; i < 11; ++i) {
             u32x4 v = areg[i];
             asm volatile("" : "+v"(v));
-            if (VAR >= 5) {
+            if (VAR == 10) {
+                // epilogue-style statistics on packed bf16 pairs with v_dot2c_f32_bf16
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2 pk = __builtin_bit_cast(bf16x2, v[e]);
+                    acc0 = __builtin_amdgcn_fdot2_f32_bf16(pk, pk, acc0, false);
+                    acc1 = __builtin_amdgcn_fdot2_f32_bf16(pk, __builtin_bit_cast(bf16x2, 0x3f803f80u), acc1, false);
+                }
+                v = u32x4{__float_as_uint(acc0), __float_as_uint(acc1), v[2], v[3]};
+            } else if (VAR >= 5) {
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -70,18 +80,18 @@ int main()
     unsigned long long* d; float* s; float2* ab;
     hipMalloc(&d, 32 * 8); hipMalloc(&s, 512 * 4); hipMalloc(&ab, 4096);
     hipMemset(ab, 0x3f, 4096);
-    const char* names[] = {"full item (affine+SiLU, mask, ds_write)", "ds_write only", "affine only, mask, ds_write", "SiLU, no mask, ds_write", "SiLU, mask, no ds_write", "unpack", "unpack, pk_mul", "unpack, pk_mul, pk_add", "unpack, pk_mul, pk_add, cvt_pk", "unpack, pk_mul, pk_add, cvt_pk, cndmask"};
+    const char* names[] = {"full item (affine+SiLU, mask, ds_write)", "ds_write only", "affine only, mask, ds_write", "SiLU, no mask, ds_write", "SiLU, mask, no ds_write", "unpack", "unpack, pk_mul", "unpack, pk_mul, pk_add", "unpack, pk_mul, pk_add, cvt_pk", "unpack, pk_mul, pk_add, cvt_pk, cndmask", "8 x v_dot2c_f32_bf16"};
     for (int swap = 0; swap < 2; ++swap)
     for (int iters : {0, 6000}) {
         hipMemset(d, 0, 32 * 8);
         printf("timed waves are the %s ones of the block; ", swap ? "OLDER (0-3)" : "younger (4-7)");
         if (swap) continue;
         run<0, false>(d, s, ab, iters); run<1, false>(d, s, ab, iters); run<2, false>(d, s, ab, iters); run<3, false>(d, s, ab, iters); run<4, false>(d, s, ab, iters);
-        run<5, false>(d, s, ab, iters); run<6, false>(d, s, ab, iters); run<7, false>(d, s, ab, iters); run<8, false>(d, s, ab, iters); run<9, false>(d, s, ab, iters);
+        run<5, false>(d, s, ab, iters); run<6, false>(d, s, ab, iters); run<7, false>(d, s, ab, iters); run<8, false>(d, s, ab, iters); run<9, false>(d, s, ab, iters); run<10, false>(d, s, ab, iters);
         unsigned long long h[32];
         hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
         printf("%s:\n", iters ? "next to an MFMA-streaming wave" : "alone on the SIMD");
-        for (int i = 0; i < 10; ++i) printf("  %-44s %7.1f cycles per item\n", names[i], (double)h[i] / (64.0 * 11.0));
+        for (int i = 0; i < 11; ++i) printf("  %-44s %7.1f cycles per item\n", names[i], (double)h[i] / (64.0 * 11.0));
     }
     return 0;
 }
