@@ -316,3 +316,21 @@ def test_persistent_kernel_on_ragged_tiles_matches_free_running_and_fp32(synth, 
     # image borders: the rows / columns covered by partial tiles must be as accurate as the interior
     edge = max(maxerr(e_pr[:, :, -4:, :], e32[:, :, -4:, :]), maxerr(e_pr[:, :, :, -8:], e32[:, :, :, -8:]))
     assert edge < 2e-2, edge
+
+
+def test_other_width_base192_two_levels(synth):
+    """A width the kernels were not tuned for (base 192, ch_mult (1,2): 192 and 384 channels -> a half-empty second N tile
+    in the persistent kernel, 24/48 channels per GroupNorm group, generic stem/head because 192 is not 32/64/128):
+    fp32 mode against the CPU oracle on one sample, bf16 mode against fp32 on the batch."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 192, (1, 2)))
+    B, S = 4, 128
+    g = torch.Generator("cpu").manual_seed(7)
+    x = torch.randn((B, 3, S, S), generator=g); z = torch.from_numpy(synth.synth_z(B)); t = torch.tensor([999, 600, 300, 10])
+    e32 = make_net(sd, 192, (1, 2))(to_dev(x), to_dev(z), to_dev(t))
+    with torch.no_grad():
+        ref = ref_unet.unet_forward(ref_unet.as_torch_sd(sd), x[1:2], z[1:2], t[1:2])
+    assert maxerr(e32[1:2], ref) < TOL_EPS_FP32, maxerr(e32[1:2], ref)
+    e16 = make_net(sd, 192, (1, 2), dtype="bf16")(to_dev(x), to_dev(z), to_dev(t))
+    d = maxerr(e16, e32)
+    print(f"base 192 @128px: fp32 vs oracle {maxerr(e32[1:2], ref):.2e}; bf16 vs fp32 {d:.3e}")
+    assert torch.isfinite(e16).all() and d < 2e-2, d
