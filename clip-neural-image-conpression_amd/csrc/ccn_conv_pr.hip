@@ -207,7 +207,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 const bool ok = i < 10 ? (((rowm >> i) & 1u) && colv) : xv;
                 if (gn) {
                     const u32x4 tr = gk.template apply<true>(v);
-                    v = u32x4{ok ? tr[0] : 0u, ok ? tr[1] : 0u, ok ? tr[2] : 0u, ok ? tr[3] : 0u};   // padding stays zero
+                    v = u32x4{0u, 0u, 0u, 0u};                                  // padding stays zero
+                    if (ok) v = tr;                                             // (exec-masked move: scalar ops instead of 4 selects)
                 }
                 const int px = i < 10 ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
                 const int sw = i < 10 ? (pc >> 1) : 0;                       // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     const int it = q * 4 + i;
                     const unsigned off = item_off(eb, it);
                     const u32x4 sv = *(const u32x4*)(stg + sbase + ((it >> 1) * 32 + (it & 1) * 16) * L::SP);
-                    const float mk = off < OOB ? 1.0f : 0.0f;             // masked items contribute nothing to the statistics
+                    const bool live = off < OOB;                          // masked items contribute nothing to the statistics
                     float x[8];
                     Vec16<T>::unpack(sv, x);
                     if constexpr (RES) {
@@ -353,8 +354,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
+                    if (live) {                                           // exec-masked: costs scalar ops, not 8 VALU multiplies
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float u = x[e] * mk; s1[e] += u; s2[e] = fmaf(u, x[e], s2[e]); }
+                        for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
+                    }
                     asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
                     asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
                     __builtin_amdgcn_sched_barrier(0);
