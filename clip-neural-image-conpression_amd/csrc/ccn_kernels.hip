@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const T* __restrict__ x, co
     }
 }
 // The same pass with the GroupNorm finalize folded in: every workgroup first reduces the producer's partial sums of its
-// sample (G groups x a few hundred slots, L2 resident; same summation order as gn_finalize_kernel, so the same bits) and
+// sample (G groups x a few hundred slots, L2 resident; a fixed summation order, so deterministic) and
 // forms its threads' scale/shift in registers -- one launch and one ~5 us dependency step less per pre-activated conv.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_act_fused_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C,
@@ -560,18 +560,44 @@ hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, in
 }
 
 // ---- GroupNorm finalize ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ part, int G, int n_sp, int n_nt, int bn,
-                                                          int cpg, int C, double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float2* __restrict__ ab)
+// One workgroup of 256 threads per (sample, group): the launch is pure latency (a dependency step between two convs), so
+// the slot loop is spread over four waves (plain loads: the producer kernel has completed) and combined in a fixed order.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict__ part, int G, int n_sp, int n_nt, int bn,
+                                                           int cpg, int C, double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float2* __restrict__ ab)
 {
-    const int bg = blockIdx.x;
-    gn_reduce_group(part, bg / G, bg % G, G, n_sp * n_nt, n_nt, bn, cpg, C, count, gamma, beta, eps, ab, threadIdx.x);
+    __shared__ double red[4][2];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jlo = (g * cpg) / bn, jhi = ((g + 1) * cpg - 1) / bn, nj = jhi - jlo + 1, ne = n_sp * nj;
+    const float2* base = part + (size_t)(b * G + g) * n_sp * n_nt;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = tid; e < ne; e += 256) {
+        const int sp = e / nj, j = jlo + (e - sp * nj);
+        const float2 v = base[(size_t)sp * n_nt + j];
+        s1 += (double)v.x; s2 += (double)v.y;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
+    __syncthreads();
+    s1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    s2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
+        const double sc = (double)gamma[c] * rstd;
+        // pair-interleaved: channels (2p, 2p+1) -> {scale, scale, shift, shift} (see GnCoef::load)
+        float* const row = (float*)(ab + (size_t)b * C) + 4 * (c >> 1) + (c & 1);
+        row[0] = (float)sc; row[2] = (float)((double)beta[c] - mean * sc);
+    }
 }
 
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C, double count,
                               const float* gamma, const float* beta, float eps, float2* ab, hipStream_t s)
 {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, part, G, n_sp, n_nt, bn, cpg, C, count, gamma, beta, eps, ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, part, G, n_sp, n_nt, bn, cpg, C, count, gamma, beta, eps, ab);
     return hipGetLastError();
 }
 
