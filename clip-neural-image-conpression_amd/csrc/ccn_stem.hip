@@ -3,13 +3,14 @@
 // K = img_ch*9 = 27 is one MFMA K-block (32): the contraction is 2 x v_mfma_f32_32x32x16_bf16 per 32 pixels x 32 channels
 // and costs nothing; the layer is bound by the 128 x H x W NHWC tensor it WRITES (67 MB at C2 / batch 8) and by the VALU
 // work around it.  The generic implicit-GEMM kernel staged an im2col tile through LDS and transposed the result through
-// LDS again (112 us, 0.6 TB/s).  Here nothing goes through LDS:
+// LDS again (112 us, 0.6 TB/s).  Here only the output transpose touches LDS:
 //   * the weights (A operand, [channel][k]) sit in registers for the whole kernel, host-packed in fragment order, with the
 //     bias folded in as k = 27 against a constant-one im2col element;
 //   * a lane builds its im2col fragment (B operand: pixel r, k = 16s + 8h .. +7) with 16 masked 4-byte loads straight from
 //     the image (6 MB, L1/L2 resident); the per-lane k -> (channel, dy, dx) table is computed once;
-//   * with the operands in this order a lane's accumulator quad is 4 consecutive channels of ONE pixel: 8-byte stores
-//     straight to NHWC, and the next GroupNorm's statistics accumulate per lane over the wave's pixels and are reduced once.
+//   * with the operands in this order a lane's accumulator quad is 4 consecutive channels of ONE pixel; the tile goes
+//     through a per-wave LDS strip so that the NHWC stores are whole 256-byte pixel rows, and the next GroupNorm's
+//     statistics accumulate per lane over the wave's pixels and are reduced once.
 #include "ccn_device.h"
 
 namespace ccn {
@@ -17,6 +18,8 @@ namespace ccn {
 template <int NT>
 __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int upw)
 {
+    constexpr int TRP = NT * 64 + 16;                              // strip pitch in bytes (C bf16 + pad: conflict-free 8-byte writes)
+    __shared__ __attribute__((aligned(16))) unsigned char tr[4 * 32 * TRP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int H = a.Hin, W = a.Win, C = a.Cout, HW = H * W;
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
         }
         const bool pv = x < W;
         const float mk = pv ? 1.0f : 0.0f;
-        const unsigned obase = (unsigned)(((b * H + y) * W + x) * C + 4 * h) * 2u;
+        // accumulators -> the wave's LDS strip [32 pixels][C bf16 (+16 B pad)] -> 16-byte stores, 256 contiguous bytes per pixel:
+        // direct 8-byte stores from the accumulator layout reached only 1.3 TB/s (32 scattered 16-byte pieces per instruction)
+        unsigned char* const strip = tr + wave * (32 * TRP);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -111,12 +116,21 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
                 const float c0 = acc[j][g * 4], c1 = acc[j][g * 4 + 1], c2 = acc[j][g * 4 + 2], c3 = acc[j][g * 4 + 3];
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 pk = {pack_bf2(c0, c1), pack_bf2(c2, c3)};
-                const bool cv = j * 32 + g * 8 + 4 * h < C;
-                __builtin_amdgcn_raw_buffer_store_b64(pk, osrd, (pv && cv) ? obase + (unsigned)(j * 32 + g * 8) * 2u : OOB, 0, 0);
+                *(u32x2*)(strip + r * TRP + (j * 32 + g * 8 + 4 * h) * 2) = pk;
                 const float t = (c0 + c1) + (c2 + c3);
                 s1[j][g] = fmaf(t, mk, s1[j][g]);
                 s2[j][g] = fmaf(fmaf(c0, c0, c1 * c1) + fmaf(c2, c2, c3 * c3), mk, s2[j][g]);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // same wave: LDS is in order
+        constexpr int SL = NT * 4;                                     // 16-byte slices per pixel
+#pragma unroll
+        for (int it = 0; it < (32 * SL) / 64; ++it) {
+            const int idx = it * 64 + lane, pxl = idx / SL, sl = idx - pxl * SL;
+            const u32x4 v16 = *(const u32x4*)(strip + pxl * TRP + sl * 16);
+            const bool ok = x0 + pxl < W && sl * 8 < C;
+            __builtin_amdgcn_raw_buffer_store_b128(v16, osrd, ok ? (unsigned)(((b * H + y) * W + x0 + pxl) * C + sl * 8) * 2u : OOB, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // strip read before the next unit rewrites it
     }
     if (!a.part) return;
     // wave reduction over the 32 pixel lanes of each half, then quads -> GroupNorm groups through a few LDS words
