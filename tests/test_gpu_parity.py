@@ -334,3 +334,21 @@ def test_other_width_base192_two_levels(synth):
     d = maxerr(e16, e32)
     print(f"base 192 @128px: fp32 vs oracle {maxerr(e32[1:2], ref):.2e}; bf16 vs fp32 {d:.3e}")
     assert torch.isfinite(e16).all() and d < 2e-2, d
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 72, 104), (8, 40, 48), (5, 136, 200), (2, 264, 136), (16, 128, 128)])
+def test_c2_architecture_odd_shapes(synth, c2_sd, B, H, W):
+    """Batch / image sizes that change which kernel takes each layer (tile counts decide between the persistent kernel, its
+    split-K form, the 4-row kernel and the generic one) and that leave partial tiles everywhere: fp32 mode against the CPU
+    oracle on the last sample of the batch, bf16 mode against fp32 on the whole batch."""
+    g = torch.Generator("cpu").manual_seed(B * 1000 + H + W)
+    x = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B)); t = torch.randint(0, 1000, (B,), generator=g)
+    e32 = make_net(c2_sd, 128, (1, 2, 2))(to_dev(x), to_dev(z), to_dev(t))
+    with torch.no_grad():
+        ref = ref_unet.unet_forward(ref_unet.as_torch_sd(c2_sd), x[-1:], z[-1:], t[-1:])
+    d32 = maxerr(e32[-1:], ref)
+    assert d32 < TOL_EPS_FP32, (B, H, W, d32)
+    e16 = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")(to_dev(x), to_dev(z), to_dev(t))
+    d16 = maxerr(e16, e32)
+    print(f"B={B} {H}x{W}: fp32 vs oracle {d32:.2e}; bf16 vs fp32 {d16:.3e}")
+    assert torch.isfinite(e16).all() and d16 < 2e-2, (B, H, W, d16)
