@@ -168,7 +168,7 @@ def main() -> None:
 
     if rank == 0:
         line = {
-            "metric": "images/sec @256px 50-step DDIM, batch=8/GPU", "value": round(value, 3), "unit": "images/sec",
+            "metric": f"images/sec @{S}px {T}-step DDIM, batch={B}/GPU", "value": round(value, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{S}px base={args.base} ch_mult={ch_mult} {T}-step DDIM (eta=0), batch={B}/GPU, "

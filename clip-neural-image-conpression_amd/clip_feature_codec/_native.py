@@ -49,6 +49,16 @@ SIGNATURES = {
     "ccn_profile_read": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f32), ctypes.POINTER(c_i32),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
     "ccn_algorithmic_work": (c_i32, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ccn_train_create": (c_i32, [ctypes.POINTER(CcnConfig), ctypes.POINTER(c_vp)]),
+    "ccn_train_destroy": (c_i32, [c_vp]),
+    "ccn_train_num_params": (c_i32, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
+    "ccn_train_param_info": (c_i32, [c_vp, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), ctypes.POINTER(c_i32),
+                                     ctypes.POINTER(c_i64)]),
+    "ccn_train_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
+    "ccn_train_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "ccn_train_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "ccn_mse_loss_grad": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "ccn_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "ccn_last_error": (ctypes.c_char_p, []),
     "ccn_version": (ctypes.c_char_p, []),
 }
@@ -251,6 +261,99 @@ class NativeUNet:
         f, b = ctypes.c_double(), ctypes.c_double()
         check(self.lib.ccn_algorithmic_work(self.h, B, H, W, ctypes.byref(f), ctypes.byref(b)))
         return f.value, b.value
+
+
+class NativeTrainer:
+    """One ccn_trainer_t: the training forward + backward of a CLIPCondUNet over a flat fp32 parameter buffer."""
+
+    def __init__(self, z_dim: int, base: int, ch_mult: Sequence[int], time_dim: int, img_ch: int,
+                 groups: int = 8, dtype="fp32", device="cuda") -> None:
+        self.lib = load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("NativeTrainer needs a HIP device ('cuda'); there is no CPU fallback")
+        self.dtype = dtype_code(dtype)
+        cfg = CcnConfig(z_dim, base, len(ch_mult), (c_i32 * 8)(*list(ch_mult)), time_dim, img_ch, groups, self.dtype)
+        self.z_dim, self.img_ch = z_dim, img_ch
+        h = c_vp()
+        with torch.cuda.device(self.device):
+            check(self.lib.ccn_train_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self._ws: Dict[Tuple[int, int, int], Workspace] = {}
+        n, total = c_i32(), c_i64()
+        check(self.lib.ccn_train_num_params(self.h, ctypes.byref(n), ctypes.byref(total)))
+        self.total = int(total.value)
+        self.layout: List[Tuple[str, Tuple[int, ...], int]] = []
+        for i in range(n.value):
+            name, shape, nd, off = ctypes.c_char_p(), (c_i64 * 4)(), c_i32(), c_i64()
+            check(self.lib.ccn_train_param_info(self.h, i, ctypes.byref(name), shape, ctypes.byref(nd), ctypes.byref(off)))
+            self.layout.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), int(off.value)))
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.ccn_train_destroy(self.h)
+            self.h = None
+            self._ws.clear()
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace(self, B: int, H: int, W: int) -> Workspace:
+        key = (B, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = c_sz()
+            check(self.lib.ccn_train_workspace_bytes(self.h, B, H, W, ctypes.byref(n)))
+            self._ws.clear()                      # one live shape at a time: the activations of a step are large
+            ws = Workspace(n.value, self.device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, flat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        B, C, H, W = x.shape
+        if C != self.img_ch or z.shape != (B, self.z_dim) or t.shape != (B,) or flat.numel() != self.total:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, z {tuple(z.shape)}, t {tuple(t.shape)}, params {flat.numel()}")
+        ws = self.workspace(B, H, W)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(self.lib.ccn_train_forward(self.h, flat.data_ptr(), x.data_ptr(), z.data_ptr(), t.data_ptr(), out.data_ptr(),
+                                             B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))
+        return out
+
+    def backward(self, flat: torch.Tensor, gflat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, d_eps: torch.Tensor) -> None:
+        B, C, H, W = x.shape
+        ws = self.workspace(B, H, W)
+        with torch.cuda.device(x.device):
+            check(self.lib.ccn_train_backward(self.h, flat.data_ptr(), gflat.data_ptr(), x.data_ptr(), z.data_ptr(), d_eps.data_ptr(),
+                                              B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))
+
+
+def mse_loss_grad(eps: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
+    """F.mse_loss(eps, target) and d loss / d eps in one pass (train/diffusion_train.py:124)."""
+    lib = load_library()
+    eps = require_dev(eps, "eps"); target = require_dev(target, "target")
+    loss = torch.empty((), dtype=torch.float32, device=eps.device)
+    d = torch.empty_like(eps) if want_grad else None
+    scratch = torch.empty(1024, dtype=torch.float32, device=eps.device)
+    with torch.cuda.device(eps.device):
+        check(lib.ccn_mse_loss_grad(eps.data_ptr(), target.data_ptr(), eps.numel(), loss.data_ptr(), ptr(d), scratch.data_ptr(),
+                                    current_stream(eps.device)))
+    return loss, d
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int) -> None:
+    """One torch.optim.AdamW update over flat fp32 buffers, in place."""
+    lib = load_library()
+    for name, tns in (("params", p), ("grads", g), ("exp_avg", m), ("exp_avg_sq", v)):
+        if not (tns.is_cuda and tns.dtype == torch.float32 and tns.is_contiguous() and tns.numel() == p.numel()):
+            raise ValueError(f"{name} must be a contiguous fp32 HIP tensor of {p.numel()} elements")
+    with torch.cuda.device(p.device):
+        check(lib.ccn_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+                                 float(beta2), float(eps), float(weight_decay), int(step), current_stream(p.device)))
 
 
 # ---- stateless ops --------------------------------------------------------------------------------

@@ -1,13 +1,16 @@
 """CLIPCondUNet with the reference's constructor, state-dict keys and ``forward(x_t, z_clip, t)``,
 evaluated by the hand-written gfx950 kernels of libccn_hip.so.
 
-Drop-in for ``models/unet.py:42-106`` of the reference on the inference path:
+Drop-in for ``models/unet.py:42-106`` of the reference:
   * ``CLIPCondUNet(z_dim, base, ch_mult, time_dim, img_ch)`` registers the same module tree
     (``time_proj.{0,2}``, ``z_proj.0``, ``in_conv``, ``down.{i}``, ``mid1``, ``mid2``, ``up.{i}``,
     ``out_norm``, ``out``), so ``load_state_dict(torch.load(ckpt), strict=True)`` works unchanged and
     default initialisation consumes the torch RNG in the same order as the reference.
   * ``forward`` takes NCHW fp32 ``x_t``, ``(B, z_dim)`` ``z_clip``, ``(B,)`` int64 ``t`` and returns eps
     with the shape / dtype / device of ``x_t``.
+  * in ``.train()`` mode with gradients enabled, ``forward`` returns an eps that carries an autograd node whose backward is
+    the library's hand-written backward pass (``train/diffusion_train.py`` of this package), so
+    ``F.mse_loss(net(x_t, z, t), noise).backward()`` fills ``p.grad`` of every parameter.
   * ``sample_ddim`` is the fused fast path ``DDIMSampler.sample`` uses: the whole loop as one hipGraph.
 
 The ``torch.nn`` leaves only hold parameters; no torch operator runs in ``forward``.  Tensors must
@@ -121,13 +124,30 @@ class CLIPCondUNet(nn.Module):
             self._nat, self._nat_key = nat, key
         return self._nat
 
+    def train_state(self, device=None):
+        """Trainer handle and flat parameter buffers (parameters become views into one fp32 buffer on first use)."""
+        from ..train.diffusion_train import TrainState
+        params = list(self.parameters())
+        dev = torch.device(device) if device is not None else params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"CLIPCondUNet is on {dev}: the training step only runs on a HIP device (no CPU fallback)")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        st = getattr(self, "_train_state", None)
+        if st is None or st.dtype != self.compute_dtype or st.trainer.device != dev or not st.fp.intact():
+            if st is not None:
+                st.trainer.close()
+            st = TrainState(self, self.compute_dtype, dev)
+            object.__setattr__(self, "_train_state", st)
+        return st
+
     # ------------------------------------------------------------------ the reference interface
     def forward(self, x_t: torch.Tensor, z_clip: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        if torch.is_grad_enabled() and self.training and not self._warned_grad:
-            warnings.warn("CLIPCondUNet (MI355X build): forward is inference-only in this round; "
-                          "the returned eps carries no autograd graph", stacklevel=2)
-            self._warned_grad = True
         out_dtype = x_t.dtype
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            # training forward (train/diffusion_train.py:123): activations kept, autograd node with the library's backward
+            eps = self.train_state(x_t.device).apply(x_t.float(), z_clip.float(), t)
+            return eps if out_dtype == torch.float32 else eps.to(out_dtype)
         eps = self.native(x_t.device).forward(x_t, z_clip, t)
         return eps if out_dtype == torch.float32 else eps.to(out_dtype)
 

@@ -32,6 +32,11 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(CCN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
     } while (0)
 
+}  // namespace
+// ccn_train.hip reports its failures through the same thread-local message
+extern "C" void ccn_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
+namespace {
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -26,7 +26,9 @@ __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <int AK, int IS> struct HaloGeom {
     static constexpr int HOFF = AK == A_NHWC ? 1 : 0;
-    static constexpr int ROWS = AK == A_NHWC ? (IS * 3 + 3) : 4;          // IS*(TH-1)+3 with TH = 4
+    // IS*(TH-1)+3 with TH = 4; one more row at stride 2 so that a 4x4 kernel (taps -1..2: the data gradient of the
+    // ConvTranspose, ccn_train.hip) fits the same staging
+    static constexpr int ROWS = AK == A_NHWC ? (IS == 1 ? 6 : 10) : 4;
     static constexpr int PITCH = AK == A_NHWC ? (IS == 1 ? 34 : 66) : 32;  // >= IS*(TW-1)+3 with TW = 32
     static constexpr int BYTES = ROWS * PITCH * 128;
 };

@@ -1,0 +1,84 @@
+// Internal declarations of the training-step kernels (ccn_train_kernels.hip) used by the host side (ccn_train.hip).
+// The step they implement is the body of the reference's training loop, train/diffusion_train.py:119-124,137-140:
+// eps_hat = net(x_t, z, t) with every activation kept, then the backward pass of that forward for a given d(eps_hat).
+#pragma once
+#include "ccn_internal.h"
+
+namespace ccn {
+
+// ---- weight repacking on the device (the fp32 master weights change every optimiser step) ------------------------
+// Destination: the [tap][N_pad][K_pad] operand layout of the implicit-GEMM kernels (ccn_kernels.hip), element type T.
+enum PackMode {
+    PK_CONV3 = 0,     // Conv2d (O, I, 3, 3)           -> forward operand, 9 taps,  N = O, K = I
+    PK_CONVT = 1,     // ConvTranspose2d (I, O, 4, 4)  -> forward operand, 16 taps, N = O, K = I
+    PK_DG3S1 = 2,     // Conv2d 3x3 s1                 -> data-gradient operand: taps flipped, N = I, K = O
+    PK_DG3S2 = 3,     // Conv2d 3x3 s2                 -> data-gradient operand for the ConvTranspose kernel: 4x4 taps, row/col 3 zero
+    PK_DGT = 4,       // ConvTranspose2d 4x4 s2        -> data-gradient operand for the stride-2 kernel run with 16 taps
+    PK_STEM = 5,      // Conv2d (O, img_ch, 3, 3)      -> im2col operand, 1 "tap", K = img_ch * 9
+    PK_HEAD_DG = 6,   // Conv2d (img_ch, C, 3, 3)      -> data gradient through the im2col kernel: N = C, K = img_ch * 9, taps flipped
+};
+hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s);
+
+// ---- GroupNorm ------------------------------------------------------------------------------------------------------
+// partial sums -> scale/shift table (as gn_finalize) plus (mean, rstd) per (sample, group)
+hipError_t launch_gn_stats(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C, double count,
+                           const float* gamma, const float* beta, float eps, float2* ab, float2* stats, hipStream_t s);
+
+struct GnBwdGeom { int nslb, pstep, ppb, nblk, zblocks; };
+GnBwdGeom gn_bwd_geom(int dtype, int HW, int C);
+// pass 1: per (sample, pixel block, channel) sums of da and da * xhat, da = dA * silu'(a x + c) (or dA)
+hipError_t launch_gn_bwd_reduce(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, float2* part,
+                                int B, int HW, int C, int cpg, int G, int silu, hipStream_t s);
+// per (sample, group): m1 = mean(gamma da), m2 = mean(gamma da xhat); dgamma += sum da xhat, dbeta += sum da
+hipError_t launch_gn_bwd_finalize(const float2* part, int nblk, int B, int C, int cpg, int G, double count, const float* gamma,
+                                  float2* gstat, float* dgamma, float* dbeta, hipStream_t s);
+// pass 2: dx = a da - rstd (m1 + xhat m2) [+ addend]; with FiLM (blocks.py:22-25): out = dx (1 + s) and per-block sums of dx, dx * x
+hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, const float2* gstat,
+                               const void* addend, void* out, const float* film, int film_bstride, float2* fpart,
+                               int B, int HW, int C, int cpg, int G, int silu, hipStream_t s);
+hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, int B, int C,
+                                    hipStream_t s);
+// per-channel sum over (B, HW) of an NHWC tensor, added to `db` (bias gradients); scratch: B * nblk * C floats
+hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s);
+// per-channel sum of an NCHW fp32 tensor, added to db
+hipError_t launch_nchw_chansum(const float* x, float* db, int B, int C, int64_t hw, hipStream_t s);
+
+// ---- weight gradients -------------------------------------------------------------------------------------------------
+struct WgArgs {
+    const void* x;            // A source NHWC T [B][Hin][Win][Cin] (the forward conv's raw input)
+    const float2* gn_ab;      // forward prologue GroupNorm (+SiLU) to redo on the fly, or null
+    const void* dy;           // NHWC T [B][Hout][Wout][Cout]
+    float* part;              // [nsplit][taps_w][Cout][Cin] fp32 partial sums
+    int B, Hin, Win, Cin, Hout, Wout, Cout, MH, MW, OS, npar, ntaps, taps_w, n_ty, n_tx, nsplit;
+    int tapinfo[16];        // as ConvArgs::tapinfo
+    __host__ __device__ int tapinfo_dy(int i) const { return (tapinfo[i] & 3) - 1; }
+    __host__ __device__ int tapinfo_dx(int i) const { return ((tapinfo[i] >> 2) & 3) - 1; }
+    __host__ __device__ int tapinfo_w(int i) const { return tapinfo[i] >> 4; }
+};
+int wgrad_nsplit(int kind, int B, int MH, int MW, int Cin, int Cout);
+hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s);
+hipError_t wgrad_prepare();
+// grads[(o*I + i)*taps + t] (Conv2d) or grads[(i*O + o)*taps + t] (ConvTranspose2d) += sum over splits
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int transposed, float* grad, hipStream_t s);
+// stem / head weights: G[c][ch][t] = sum_q X[q][c] * img[ch][q + sgn * d_t]; X NHWC T (optionally GroupNorm-ed, no SiLU), img NCHW fp32
+int wsmall_blocks(int H);
+hipError_t launch_wgrad_small(int dtype, const void* xn, const float2* gn_ab, const float* img, int img_ch, int sgn, float* part,
+                              int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_wsmall_reduce(const float* part, int nblk, int C, int img_ch, int head, float* grad, hipStream_t s);
+
+// ---- conditioning (small fp32 linears) ----------------------------------------------------------------------------------
+hipError_t launch_tlinear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, float* u, int R, int K, int N,
+                              int silu, hipStream_t s);
+hipError_t launch_tlinear_dw(const float* dy, int lddy, const float* x, int ldx, float* dW, float* db, int R, int K, int N, hipStream_t s);
+hipError_t launch_tlinear_dx(const float* dy, int lddy, const float* W, float* dx, int lddx, int R, int K, int N, int accumulate, hipStream_t s);
+hipError_t launch_silu_bwd(float* du, const float* dy, const float* u, int64_t n, hipStream_t s);
+hipError_t launch_add2(float* y, const float* a, const float* b, int64_t n, hipStream_t s);
+
+// ---- loss and optimiser ---------------------------------------------------------------------------------------------------
+// loss = mean((eps - target)^2) (F.mse_loss, train/diffusion_train.py:124); d_eps = 2 (eps - target) / n; scratch >= 1024 floats
+hipError_t launch_mse_loss_grad(const float* eps, const float* target, int64_t n, float* loss, float* d_eps, float* scratch, hipStream_t s);
+// torch.optim.AdamW step (train/diffusion_train.py:105,138): decoupled weight decay, bias-corrected moments
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                        int step, hipStream_t s);
+
+}  // namespace ccn

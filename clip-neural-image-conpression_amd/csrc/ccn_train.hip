@@ -1,0 +1,698 @@
+// Host side of the training step: ccn_train_* of include/ccn_hip.h.
+//
+// Reference: the loop body of train/diffusion_train.py:119-124,137-140 -- eps_hat = net(x_t, z, t); loss = mse(eps_hat, noise);
+// loss.backward(); opt.step().  ccn_train_forward is CLIPCondUNet.forward (models/unet.py:81-106) with every tensor the
+// backward needs kept in the caller's workspace; ccn_train_backward takes d loss / d eps_hat and ACCUMULATES the gradient of
+// every parameter into a flat fp32 buffer laid out like the flat parameter buffer (the order of CLIPCondUNet.state_dict()).
+//
+// Parameters are read from the caller's flat fp32 buffer on every call (they change with every optimiser step) and repacked on
+// the device into the operand layouts of the convolution kernels.  Activations and activation gradients are NHWC in the
+// handle's arithmetic type (fp32 parity mode / bf16); GroupNorm statistics, FiLM, the conditioning MLP, all parameter
+// gradients and the optimiser state are fp32.
+//
+// Layout of the workspace: [shared scratch regions][tensors in allocation order].  Every call walks the fixed layer list with a
+// bump allocator, so the forward walk of ccn_train_backward (launches disabled) finds the tensors the forward call wrote.
+#include "../../include/ccn_hip.h"
+#include "ccn_train.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ccn;
+
+extern "C" void ccn_internal_set_error(const char* msg);   // ccn_api.hip: thread-local message behind ccn_last_error()
+
+namespace {
+
+int tfail(int code, const std::string& msg) { ccn_internal_set_error(msg.c_str()); return code; }
+#define THIP(expr)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct PInfo { std::string name; std::vector<int64_t> shape; size_t off = 0; size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; } };
+
+struct TConvW {
+    int kind = KIND_C3S1, Cin = 0, Cout = 0;
+    int pw = -1, pb = -1;                       // parameter indices (weight, bias)
+    int BN = 0, Cin_pad = 0, Cout_pad = 0;      // forward operand
+    int dkind = KIND_C3S1, dBN = 0, dCin_pad = 0, dCout_pad = 0, dtaps = 9;   // data-gradient operand (roles of Cin / Cout swapped)
+    void* wf = nullptr; void* wd = nullptr;
+};
+struct TNorm { int C = 0, pg = -1, pb = -1; };
+struct TLin { int pw = -1, pb = -1, N = 0, K = 0; };
+struct TRes { int C = 0; TNorm n1, n2; TConvW c1, c2; TLin fs, fh; int film_off = 0; };
+enum LType { L_STEM, L_RES, L_DOWN, L_UP, L_HEAD };
+struct Layer { LType type; int idx; };
+
+struct TT {                                     // an NHWC activation and the partial sums of the GroupNorm that reads it
+    void* p = nullptr; int C = 0, H = 0, W = 0;
+    float2* part = nullptr; int n_sp = 0, n_nt = 0, bn = 0;
+};
+
+struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, scr_small = 0, tensors = 0, total = 0; };
+
+}  // namespace
+
+struct ccn_trainer_s {
+    ccn_config_t cfg{};
+    int elem = 4, G = 8;
+    std::vector<PInfo> params;
+    size_t total = 0;
+    TConvW stem, head;
+    TNorm out_norm;
+    TLin tp0, tp2, zp;
+    std::vector<TRes> res;
+    std::vector<TConvW> downs, ups;
+    std::vector<Layer> layers;
+    int F = 0;
+    float* zero_bias = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, ShapeInfo> shapes;
+    // state of the last forward (checked by backward)
+    int fB = 0, fH = 0, fW = 0; void* fws = nullptr; const float* fx = nullptr;
+};
+
+namespace {
+
+int add_param(ccn_trainer_s* tr, const std::string& name, std::vector<int64_t> shape)
+{
+    PInfo p; p.name = name; p.shape = std::move(shape); p.off = tr->total;
+    tr->total += align_up(p.numel(), 4);                    // 16-byte aligned views
+    tr->params.push_back(p);
+    return (int)tr->params.size() - 1;
+}
+
+// models/unet.py:45-79 registration order (the key order of state_dict())
+void build_arch(ccn_trainer_s* tr)
+{
+    const ccn_config_t& c = tr->cfg;
+    const int td = c.time_dim;
+    auto lin = [&](const std::string& n, int N, int K) { TLin l; l.N = N; l.K = K; l.pw = add_param(tr, n + ".weight", {N, K}); l.pb = add_param(tr, n + ".bias", {N}); return l; };
+    auto conv = [&](const std::string& n, int kind, int Cin, int Cout) {
+        TConvW w; w.kind = kind; w.Cin = Cin; w.Cout = Cout;
+        if (kind == KIND_CT4) w.pw = add_param(tr, n + ".weight", {Cin, Cout, 4, 4});
+        else w.pw = add_param(tr, n + ".weight", {Cout, Cin, 3, 3});
+        w.pb = add_param(tr, n + ".bias", {Cout});
+        return w;
+    };
+    auto norm = [&](const std::string& n, int C) { TNorm g; g.C = C; g.pg = add_param(tr, n + ".weight", {C}); g.pb = add_param(tr, n + ".bias", {C}); return g; };
+    tr->tp0 = lin("time_proj.0", td * 4, td);
+    tr->tp2 = lin("time_proj.2", td, td * 4);
+    tr->zp = lin("z_proj.0", td, c.z_dim);
+    tr->stem = conv("in_conv", KIND_STEM, c.img_ch, c.base);
+    tr->layers.push_back({L_STEM, 0});
+    int ch = c.base, film_off = 0;
+    auto add_res = [&](const std::string& name, int cc) {
+        TRes r; r.C = cc;
+        r.n1 = norm(name + ".norm1", cc); r.c1 = conv(name + ".conv1", KIND_C3S1, cc, cc);
+        r.n2 = norm(name + ".norm2", cc); r.c2 = conv(name + ".conv2", KIND_C3S1, cc, cc);
+        r.fs = lin(name + ".film.to_scale", cc, td); r.fh = lin(name + ".film.to_shift", cc, td);
+        r.film_off = film_off; film_off += 2 * cc;
+        tr->res.push_back(r);
+        tr->layers.push_back({L_RES, (int)tr->res.size() - 1});
+    };
+    for (int i = 0; i < c.n_mult; ++i) {
+        const int m = c.ch_mult[i];
+        add_res("down." + std::to_string(3 * i), ch);
+        add_res("down." + std::to_string(3 * i + 1), ch);
+        tr->downs.push_back(conv("down." + std::to_string(3 * i + 2), KIND_C3S2, ch, ch * m));
+        tr->layers.push_back({L_DOWN, i});
+        ch *= m;
+    }
+    add_res("mid1", ch);
+    add_res("mid2", ch);
+    for (int i = 0; i < c.n_mult; ++i) {
+        const int m = c.ch_mult[c.n_mult - 1 - i];
+        add_res("up." + std::to_string(3 * i), ch);
+        add_res("up." + std::to_string(3 * i + 1), ch);
+        tr->ups.push_back(conv("up." + std::to_string(3 * i + 2), KIND_CT4, ch, ch / m));
+        tr->layers.push_back({L_UP, i});
+        ch /= m;
+    }
+    tr->out_norm = norm("out_norm", ch);
+    tr->head = conv("out", KIND_HEAD, ch, c.img_ch);
+    tr->layers.push_back({L_HEAD, 0});
+    tr->F = film_off;
+}
+
+bool alloc_dev(ccn_trainer_s* tr, size_t bytes, void** out, std::string& err)
+{
+    void* p = nullptr;
+    THIP(hipMalloc(&p, bytes ? bytes : 4));
+    tr->allocs.push_back(p);
+    *out = p;
+    return true;
+}
+
+// operand geometry and device buffers of one convolution (forward and data-gradient operands)
+bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
+{
+    const int cke = tr->elem == 2 ? 64 : 32;
+    const int fkind = w.kind;
+    w.BN = conv_bn_for(w.Cout, fkind);
+    w.Cout_pad = (int)align_up(w.Cout, w.BN);
+    w.Cin_pad = fkind == KIND_STEM ? cke : (int)align_up(w.Cin, cke);
+    const int ftaps = fkind == KIND_CT4 ? 16 : (fkind == KIND_STEM ? 1 : 9);
+    if (!alloc_dev(tr, (size_t)ftaps * w.Cout_pad * w.Cin_pad * tr->elem, &w.wf, err)) return false;
+    if (fkind == KIND_STEM) return true;                     // the image needs no gradient
+    // data gradient: a convolution from Cout back to Cin
+    switch (fkind) {
+        case KIND_C3S1: w.dkind = KIND_C3S1; w.dtaps = 9; break;
+        case KIND_C3S2: w.dkind = KIND_CT4; w.dtaps = 16; break;
+        case KIND_CT4: w.dkind = KIND_C3S2; w.dtaps = 16; break;
+        case KIND_HEAD: w.dkind = KIND_STEM; w.dtaps = 1; break;
+    }
+    w.dBN = conv_bn_for(w.Cin, w.dkind);
+    w.dCout_pad = (int)align_up(w.Cin, w.dBN);
+    w.dCin_pad = w.dkind == KIND_STEM ? cke : (int)align_up(w.Cout, cke);
+    return alloc_dev(tr, (size_t)w.dtaps * w.dCout_pad * w.dCin_pad * tr->elem, &w.wd, err);
+}
+
+void fill_taps(int* tapinfo, int kind, bool four_by_four)
+{
+    std::memset(tapinfo, 0, 16 * sizeof(int));
+    if (kind == KIND_STEM) { tapinfo[0] = ConvArgs::make_tap(0, 0, 0); return; }
+    if (kind == KIND_CT4) {
+        // out = 2*in - 1 + k (ConvTranspose2d k=4, s=2, p=1): even out <- k in {1 (d=0), 3 (d=-1)}; odd out <- k in {0 (d=+1), 2 (d=0)}
+        static const int kk[2][2] = {{1, 3}, {0, 2}}, dd[2][2] = {{0, -1}, {1, 0}};
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        tapinfo[(py * 2 + px) * 4 + i * 2 + j] = ConvArgs::make_tap(dd[py][i], dd[px][j], kk[py][i] * 4 + kk[px][j]);
+        return;
+    }
+    if (four_by_four) {                                      // 4x4 s2 p1 convolution: in = 2 m + (k - 1), k = 0..3
+        for (int ky = 0; ky < 4; ++ky)
+            for (int kx = 0; kx < 4; ++kx) tapinfo[ky * 4 + kx] = ConvArgs::make_tap(ky - 1, kx - 1, ky * 4 + kx);
+        return;
+    }
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) tapinfo[ky * 3 + kx] = ConvArgs::make_tap(ky - 1, kx - 1, ky * 3 + kx);
+}
+
+struct Geom { int Hout, Wout, MH, MW, OS, npar, ntaps; };
+Geom geom_of(int kind, int Hin, int Win, bool four_by_four)
+{
+    Geom g{};
+    switch (kind) {
+        case KIND_C3S2: g.Hout = (Hin - 1) / 2 + 1; g.Wout = (Win - 1) / 2 + 1; g.MH = g.Hout; g.MW = g.Wout; g.OS = 1; g.npar = 1; g.ntaps = four_by_four ? 16 : 9; break;
+        case KIND_CT4: g.Hout = Hin * 2; g.Wout = Win * 2; g.MH = Hin; g.MW = Win; g.OS = 2; g.npar = 4; g.ntaps = 4; break;
+        case KIND_STEM: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 1; break;
+        default: g.Hout = Hin; g.Wout = Win; g.MH = Hin; g.MW = Win; g.OS = 1; g.npar = 1; g.ntaps = 9; break;
+    }
+    return g;
+}
+
+// One walk over the layer list.  `launch` off: only the allocation sequence (and the scratch maxima) are reproduced.
+struct Walk {
+    ccn_trainer_s* tr;
+    int B, H, W;
+    char* base; size_t off = 0;
+    bool launch;
+    hipStream_t st;
+    const float* P; float* Gd;            // flat parameters / gradients
+    ShapeInfo need;                       // scratch maxima seen by this walk
+    float *scr_wg = nullptr, *scr_col = nullptr, *scr_small = nullptr; float2 *scr_gn = nullptr, *scr_film = nullptr;
+    std::string err;
+    // conditioning buffers
+    float *temb = nullptr, *u0 = nullptr, *t1 = nullptr, *tp = nullptr, *uz = nullptr, *zpv = nullptr, *hv = nullptr, *film = nullptr;
+    float *dfilm = nullptr, *dh = nullptr, *dt1 = nullptr, *du0 = nullptr, *duz = nullptr;
+    // saved by the forward walk
+    struct ResSave { TT x, y, o; float2 *ab1, *st1, *ab2, *st2; };
+    std::vector<ResSave> rs;
+    TT stem_out; std::vector<TT> down_in, down_out, up_in, up_out;
+    TT head_in; float2 *ab_o = nullptr, *st_o = nullptr;
+
+    Walk(ccn_trainer_s* t, int B_, int H_, int W_, void* ws, bool l, hipStream_t s, const float* p, float* g)
+        : tr(t), B(B_), H(H_), W(W_), base((char*)ws), launch(l), st(s), P(p), Gd(g) {}
+
+    void* take(size_t bytes) { off = align_up(off, 256); void* p = base ? base + off : nullptr; off += bytes; return p; }
+    TT new_tensor(int C, int h, int w) { TT t; t.C = C; t.H = h; t.W = w; t.p = take((size_t)B * h * w * C * tr->elem); return t; }
+    int groups_for(int C) const { return C < tr->G ? C : tr->G; }
+    const float* par(int i) const { return P + tr->params[i].off; }
+    float* grad(int i) const { return Gd + tr->params[i].off; }
+    bool ok(hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; }
+
+    void place_scratch(const ShapeInfo& si)
+    {
+        scr_wg = (float*)take(si.scr_wg); scr_gn = (float2*)take(si.scr_gn); scr_film = (float2*)take(si.scr_film);
+        scr_col = (float*)take(si.scr_col); scr_small = (float*)take(si.scr_small);
+    }
+
+    // ---- forward pieces --------------------------------------------------------------------------------------------------
+    bool pack(const TConvW& w)
+    {
+        if (!launch) return true;
+        const int dt = tr->cfg.dtype;
+        const float* src = par(w.pw);
+        switch (w.kind) {
+            case KIND_C3S1: case KIND_C3S2:
+                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
+                return ok(launch_pack_w(dt, src, w.wd, w.kind == KIND_C3S1 ? PK_DG3S1 : PK_DG3S2, w.Cout, w.Cin, w.dtaps, w.dCout_pad, w.dCin_pad, st), "pack");
+            case KIND_CT4:
+                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONVT, w.Cout, w.Cin, 16, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
+                return ok(launch_pack_w(dt, src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad, st), "pack");
+            case KIND_STEM:
+                return ok(launch_pack_w(dt, src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad, st), "pack");
+            case KIND_HEAD:
+                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
+                return ok(launch_pack_w(dt, src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad, st), "pack");
+        }
+        return true;
+    }
+
+    // generic launch of the forward conv kernels.  `kind`: kernel family; N = output channels of this launch, K = input channels
+    bool run_conv(int kind, bool four, const void* wop, int BN, int K, int Kpad, int N, int Npad, const float* bias, const void* in, int Hin, int Win,
+                  TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out)
+    {
+        const Geom g = geom_of(kind, Hin, Win, four);
+        const int cke = tr->elem == 2 ? 64 : 32;
+        const int n_nt = Npad / BN;
+        const int th = conv_tile_rows(kind, BN, B, g.MH, g.MW, g.npar, n_nt);
+        ConvArgs a{};
+        a.in = in; a.w = wop; a.wfrag = nullptr; a.bias = bias; a.out = out_p;
+        a.gn_ab = gn_ab; a.film = film; a.res = res;
+        a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = K; a.Cin_pad = Kpad;
+        a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = N; a.Cout_pad = Npad;
+        a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
+        a.th = th; a.n_ty = ceil_div(g.MH, th); a.n_tx = ceil_div(g.MW, 32); a.n_nt = n_nt;
+        a.nchunk = Kpad / cke;
+        a.silu = 1; a.ksplit = 1;
+        a.G = groups_for(N); a.cpg = N / a.G;
+        a.nslot = a.n_ty * a.n_tx * g.npar * n_nt;
+        a.film_bstride = tr->F;
+        a.bn = BN;
+        a.fin_blocks = a.nslot;
+        a.eps_out = eps_out;
+        fill_taps(a.tapinfo, kind, four);
+        if (want_part && out) {
+            out->part = (float2*)take((size_t)B * a.G * a.nslot * sizeof(float2));
+            out->n_sp = a.n_ty * a.n_tx * g.npar; out->n_nt = n_nt; out->bn = BN;
+            a.part = out->part;
+        }
+        if (!launch) return true;
+        return ok(launch_conv(tr->cfg.dtype, kind, BN, a, st), "conv");
+    }
+    bool conv_fwd(const TConvW& w, const TT& in, TT& out, const float2* gn_ab, const float* film, const TT* res, bool want_part, const void* in_override = nullptr,
+                  float* eps_out = nullptr)
+    {
+        return run_conv(w.kind, false, w.wf, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
+                        &out, out.p, gn_ab, film, res ? res->p : nullptr, want_part, eps_out);
+    }
+    // dX = conv'(dY): N = the forward conv's Cin
+    bool conv_dgrad(const TConvW& w, const void* dy, int Hdy, int Wdy, void* dx, const void* res)
+    {
+        return run_conv(w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
+                        nullptr, dx, nullptr, nullptr, res, false, nullptr);
+    }
+    bool gn_fwd(const TT& t, const TNorm& n, float2*& ab, float2*& stats)
+    {
+        const int G = groups_for(t.C), cpg = t.C / G;
+        ab = (float2*)take((size_t)B * t.C * sizeof(float2));
+        stats = (float2*)take((size_t)B * G * sizeof(float2));
+        if (!launch) return true;
+        return ok(launch_gn_stats(t.part, B, G, t.n_sp, t.n_nt, t.bn, cpg, t.C, (double)cpg * t.H * t.W, par(n.pg), par(n.pb), 1e-5f, ab, stats, st), "gn_stats");
+    }
+
+    bool conditioning(const float* z, const int64_t* t)
+    {
+        const ccn_config_t& c = tr->cfg;
+        const int td = c.time_dim;
+        temb = (float*)take((size_t)B * td * 4); u0 = (float*)take((size_t)B * td * 16); t1 = (float*)take((size_t)B * td * 16);
+        tp = (float*)take((size_t)B * td * 4); uz = (float*)take((size_t)B * td * 4); zpv = (float*)take((size_t)B * td * 4);
+        hv = (float*)take((size_t)B * td * 4); film = (float*)take((size_t)B * tr->F * 4);
+        if (!launch) return true;
+        if (!ok(launch_temb_i64(t, temb, B, td, st), "temb")) return false;
+        if (!ok(launch_tlinear_fwd(temb, td, par(tr->tp0.pw), par(tr->tp0.pb), t1, 4 * td, u0, B, td, 4 * td, 1, st), "time_proj.0")) return false;
+        if (!ok(launch_tlinear_fwd(t1, 4 * td, par(tr->tp2.pw), par(tr->tp2.pb), tp, td, nullptr, B, 4 * td, td, 0, st), "time_proj.2")) return false;
+        if (!ok(launch_tlinear_fwd(z, c.z_dim, par(tr->zp.pw), par(tr->zp.pb), zpv, td, uz, B, c.z_dim, td, 1, st), "z_proj")) return false;
+        if (!ok(launch_add2(hv, tp, zpv, (int64_t)B * td, st), "h")) return false;
+        for (const TRes& r : tr->res) {
+            if (!ok(launch_tlinear_fwd(hv, td, par(r.fs.pw), par(r.fs.pb), film + r.film_off, tr->F, nullptr, B, td, r.C, 0, st), "film")) return false;
+            if (!ok(launch_tlinear_fwd(hv, td, par(r.fh.pw), par(r.fh.pb), film + r.film_off + r.C, tr->F, nullptr, B, td, r.C, 0, st), "film")) return false;
+        }
+        return true;
+    }
+
+    bool forward(const float* x_t, const float* z, const int64_t* t, float* eps)
+    {
+        if (launch) {
+            if (!pack(tr->stem) || !pack(tr->head)) return false;
+            for (const TRes& r : tr->res) if (!pack(r.c1) || !pack(r.c2)) return false;
+            for (const TConvW& w : tr->downs) if (!pack(w)) return false;
+            for (const TConvW& w : tr->ups) if (!pack(w)) return false;
+        }
+        if (!conditioning(z, t)) return false;
+        TT x; std::vector<TT> skips;
+        TT img; img.C = tr->cfg.img_ch; img.H = H; img.W = W;
+        for (const Layer& L : tr->layers) {
+            switch (L.type) {
+                case L_STEM: {
+                    x = new_tensor(tr->stem.Cout, H, W);
+                    if (!conv_fwd(tr->stem, img, x, nullptr, nullptr, nullptr, true, x_t)) return false;
+                    stem_out = x;
+                    break;
+                }
+                case L_RES: {
+                    const TRes& r = tr->res[L.idx];
+                    ResSave s; s.x = x;
+                    if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;
+                    s.y = new_tensor(r.C, x.H, x.W);
+                    if (!conv_fwd(r.c1, x, s.y, s.ab1, film ? film + r.film_off : nullptr, nullptr, true)) return false;
+                    if (!gn_fwd(s.y, r.n2, s.ab2, s.st2)) return false;
+                    s.o = new_tensor(r.C, x.H, x.W);
+                    if (!conv_fwd(r.c2, s.y, s.o, s.ab2, nullptr, &x, true)) return false;
+                    rs.push_back(s);
+                    x = s.o;
+                    break;
+                }
+                case L_DOWN: {
+                    const TConvW& w = tr->downs[L.idx];
+                    skips.push_back(x);
+                    TT o = new_tensor(w.Cout, x.H / 2, x.W / 2);
+                    if (!conv_fwd(w, x, o, nullptr, nullptr, nullptr, true)) return false;
+                    down_in.push_back(x); down_out.push_back(o);
+                    x = o;
+                    break;
+                }
+                case L_UP: {
+                    const TConvW& w = tr->ups[L.idx];
+                    TT o = new_tensor(w.Cout, x.H * 2, x.W * 2);
+                    TT sk = skips.back(); skips.pop_back();
+                    if (!conv_fwd(w, x, o, nullptr, nullptr, &sk, true)) return false;
+                    up_in.push_back(x); up_out.push_back(o);
+                    x = o;
+                    break;
+                }
+                case L_HEAD: {
+                    head_in = x;
+                    if (!gn_fwd(x, tr->out_norm, ab_o, st_o)) return false;
+                    TT none;
+                    if (!run_conv(KIND_HEAD, false, tr->head.wf, tr->head.BN, tr->head.Cin, tr->head.Cin_pad, tr->head.Cout, tr->head.Cout_pad,
+                                  launch ? par(tr->head.pb) : nullptr, x.p, x.H, x.W, &none, nullptr, ab_o, nullptr, nullptr, false, eps)) return false;
+                    break;
+                }
+            }
+        }
+        return true;
+    }
+
+    // ---- backward pieces ---------------------------------------------------------------------------------------------------
+    void want(size_t& slot, size_t bytes) { if (bytes > slot) slot = bytes; }
+
+    // dW (and db) of a conv: A = act(GN(x)) redone on the fly, dY given
+    bool conv_wgrad(const TConvW& w, const TT& xin, const float2* gn_ab, const void* dy, int Hdy, int Wdy)
+    {
+        const Geom g = geom_of(w.kind, xin.H, xin.W, false);
+        WgArgs a{};
+        a.x = xin.p; a.gn_ab = gn_ab; a.dy = dy; a.part = scr_wg;
+        a.B = B; a.Hin = xin.H; a.Win = xin.W; a.Cin = w.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = w.Cout;
+        a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps; a.taps_w = w.kind == KIND_CT4 ? 16 : 9;
+        a.n_ty = ceil_div(g.MH, 4); a.n_tx = ceil_div(g.MW, 32);
+        a.nsplit = wgrad_nsplit(w.kind, B, g.MH, g.MW, w.Cin, w.Cout);
+        fill_taps(a.tapinfo, w.kind, false);
+        want(need.scr_wg, (size_t)a.nsplit * a.taps_w * w.Cout * w.Cin * 4);
+        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, Hdy * Wdy, w.Cout);
+        want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
+        (void)Hdy; (void)Wdy;
+        if (!launch) return true;
+        if (!ok(launch_wgrad(tr->cfg.dtype, w.kind, a, st), "wgrad")) return false;
+        if (!ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, w.Cout, w.Cin, w.kind == KIND_CT4 ? 1 : 0, grad(w.pw), st), "wgrad_reduce")) return false;
+        return ok(launch_colsum(tr->cfg.dtype, dy, scr_col, grad(w.pb), B, g.Hout * g.Wout, w.Cout, st), "bias_grad");
+    }
+    // GroupNorm(+SiLU) backward of the norm reading tensor `x`: dA -> out (may alias dA)
+    bool gn_bwd(const TT& x, const TNorm& n, const float2* ab, const float2* stats, const void* dA, void* out, bool silu, const void* addend,
+                int film_off)
+    {
+        const int G = groups_for(x.C), cpg = x.C / G, HW = x.H * x.W;
+        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, HW, x.C);
+        want(need.scr_gn, (size_t)B * gg.nblk * x.C * sizeof(float2));
+        if (film_off >= 0) want(need.scr_film, (size_t)B * gg.nblk * x.C * sizeof(float2));
+        const float* film_r = film_off >= 0 && film ? film + film_off : nullptr;
+        float* dfilm_r = film_off >= 0 && dfilm ? dfilm + film_off : nullptr;
+        float2* gstat = (float2*)take((size_t)B * G * sizeof(float2));
+        if (!launch) return true;
+        const int dt = tr->cfg.dtype;
+        if (!ok(launch_gn_bwd_reduce(dt, x.p, dA, ab, stats, scr_gn, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_reduce")) return false;
+        if (!ok(launch_gn_bwd_finalize(scr_gn, gg.nblk, B, x.C, cpg, G, (double)cpg * HW, par(n.pg), gstat, grad(n.pg), grad(n.pb), st), "gn_bwd_finalize")) return false;
+        if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, film_r ? scr_film : nullptr, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))
+            return false;
+        if (film_r) return ok(launch_film_bwd_finalize(scr_film, gg.nblk, film_r, tr->F, dfilm_r, B, x.C, st), "film_bwd");
+        return true;
+    }
+    bool lin_bwd(const TLin& l, const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int accumulate)
+    {
+        if (!launch) return true;
+        if (!ok(launch_tlinear_dw(dy, lddy, x, ldx, grad(l.pw), grad(l.pb), B, l.K, l.N, st), "linear_dw")) return false;
+        if (dx) return ok(launch_tlinear_dx(dy, lddy, par(l.pw), dx, lddx, B, l.K, l.N, accumulate, st), "linear_dx");
+        return true;
+    }
+
+    bool backward(const float* x_t, const float* z, const float* d_eps)
+    {
+        const ccn_config_t& c = tr->cfg;
+        const int td = c.time_dim, dt = c.dtype;
+        dfilm = (float*)take((size_t)B * tr->F * 4); dh = (float*)take((size_t)B * td * 4);
+        dt1 = (float*)take((size_t)B * td * 16); du0 = (float*)take((size_t)B * td * 16); duz = (float*)take((size_t)B * td * 4);
+        TT g;                                                  // gradient w.r.t. the current tensor
+        std::vector<void*> dskip;                              // gradients waiting at the skip connections (pushed by the up path)
+        int ri = (int)rs.size() - 1, di = (int)down_in.size() - 1, ui = (int)up_in.size() - 1;
+        for (int li = (int)tr->layers.size() - 1; li >= 0; --li) {
+            const Layer& L = tr->layers[li];
+            switch (L.type) {
+                case L_HEAD: {
+                    const TConvW& w = tr->head;
+                    const TT& u = head_in;
+                    // out.weight / out.bias
+                    want(need.scr_small, (size_t)B * wsmall_blocks(H) * u.C * 27 * 4);
+                    if (launch) {
+                        if (!ok(launch_wgrad_small(dt, u.p, ab_o, d_eps, c.img_ch, -1, scr_small, B, H, W, u.C, st), "head_wgrad")) return false;
+                        if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), u.C, c.img_ch, 1, grad(w.pw), st), "head_wgrad_reduce")) return false;
+                        if (!ok(launch_nchw_chansum(d_eps, grad(w.pb), B, c.img_ch, (int64_t)H * W, st), "head_bias")) return false;
+                    }
+                    g = new_tensor(u.C, H, W);
+                    if (!conv_dgrad(w, d_eps, H, W, g.p, nullptr)) return false;
+                    if (!gn_bwd(u, tr->out_norm, ab_o, st_o, g.p, g.p, false, nullptr, -1)) return false;
+                    break;
+                }
+                case L_UP: {
+                    const TConvW& w = tr->ups[L.idx];
+                    const TT& xin = up_in[ui]; --ui;
+                    dskip.push_back(g.p);                       // x = convT(xin) + skip
+                    if (!conv_wgrad(w, xin, nullptr, g.p, g.H, g.W)) return false;
+                    TT d = new_tensor(xin.C, xin.H, xin.W);
+                    if (!conv_dgrad(w, g.p, g.H, g.W, d.p, nullptr)) return false;
+                    g = d;
+                    break;
+                }
+                case L_DOWN: {
+                    const TConvW& w = tr->downs[L.idx];
+                    const TT& xin = down_in[di]; --di;
+                    if (!conv_wgrad(w, xin, nullptr, g.p, g.H, g.W)) return false;
+                    TT d = new_tensor(xin.C, xin.H, xin.W);
+                    const void* sk = dskip.back(); dskip.pop_back();
+                    if (!conv_dgrad(w, g.p, g.H, g.W, d.p, sk)) return false;
+                    g = d;
+                    break;
+                }
+                case L_RES: {
+                    const TRes& r = tr->res[L.idx];
+                    const ResSave& s = rs[ri]; --ri;
+                    // out = x + conv2(A2), A2 = silu(gn2(F)), F = film(conv1(A1)), A1 = silu(gn1(x))
+                    if (!conv_wgrad(r.c2, s.y, s.ab2, g.p, g.H, g.W)) return false;
+                    TT g1 = new_tensor(r.C, g.H, g.W);
+                    if (!conv_dgrad(r.c2, g.p, g.H, g.W, g1.p, nullptr)) return false;
+                    if (!gn_bwd(s.y, r.n2, s.ab2, s.st2, g1.p, g1.p, true, nullptr, r.film_off)) return false;
+                    if (!conv_wgrad(r.c1, s.x, s.ab1, g1.p, g.H, g.W)) return false;
+                    TT g2 = new_tensor(r.C, g.H, g.W);
+                    if (!conv_dgrad(r.c1, g1.p, g.H, g.W, g2.p, nullptr)) return false;
+                    if (!gn_bwd(s.x, r.n1, s.ab1, s.st1, g2.p, g2.p, true, g.p, -1)) return false;
+                    g = g2;
+                    break;
+                }
+                case L_STEM: {
+                    const TConvW& w = tr->stem;
+                    want(need.scr_small, (size_t)B * wsmall_blocks(H) * w.Cout * 27 * 4);
+                    const GnBwdGeom gg = gn_bwd_geom(dt, H * W, w.Cout);
+                    want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
+                    if (launch) {
+                        if (!ok(launch_wgrad_small(dt, g.p, nullptr, x_t, c.img_ch, +1, scr_small, B, H, W, w.Cout, st), "stem_wgrad")) return false;
+                        if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), w.Cout, c.img_ch, 0, grad(w.pw), st), "stem_wgrad_reduce")) return false;
+                        if (!ok(launch_colsum(dt, g.p, scr_col, grad(w.pb), B, H * W, w.Cout, st), "stem_bias")) return false;
+                    }
+                    break;
+                }
+            }
+        }
+        // conditioning: film_r = h W_r^T + b_r for every block; h = time_proj(temb(t)) + z_proj(z)
+        if (!launch) return true;
+        bool first = true;
+        for (const TRes& r : tr->res) {
+            if (!lin_bwd(r.fs, dfilm + r.film_off, tr->F, hv, td, dh, td, first ? 0 : 1)) return false;
+            first = false;
+            if (!lin_bwd(r.fh, dfilm + r.film_off + r.C, tr->F, hv, td, dh, td, 1)) return false;
+        }
+        if (!lin_bwd(tr->tp2, dh, td, t1, 4 * td, dt1, 4 * td, 0)) return false;
+        if (!ok(launch_silu_bwd(du0, dt1, u0, (int64_t)B * 4 * td, st), "silu_bwd")) return false;
+        if (!lin_bwd(tr->tp0, du0, 4 * td, temb, td, nullptr, 0, 0)) return false;
+        if (!ok(launch_silu_bwd(duz, dh, uz, (int64_t)B * td, st), "silu_bwd")) return false;
+        return lin_bwd(tr->zp, duz, td, z, c.z_dim, nullptr, 0, 0);
+    }
+};
+
+std::string shape_key(int B, int H, int W) { return std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W); }
+
+int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return tfail(CCN_EINVAL, "B, H, W must be positive");
+    const int div = 1 << tr->cfg.n_mult;
+    if (H % div || W % div) return tfail(CCN_EINVAL, "H and W must be divisible by 2^len(ch_mult)");
+    const std::string key = shape_key(B, H, W);
+    auto it = tr->shapes.find(key);
+    if (it != tr->shapes.end()) { *out = it->second; return CCN_OK; }
+    Walk w(tr, B, H, W, nullptr, false, nullptr, nullptr, nullptr);
+    if (!w.forward(nullptr, nullptr, nullptr, nullptr) || !w.backward(nullptr, nullptr, nullptr)) return tfail(CCN_EINVAL, w.err);
+    ShapeInfo si = w.need;
+    si.tensors = align_up(w.off, 256);
+    si.total = si.tensors + align_up(si.scr_wg, 256) + align_up(si.scr_gn, 256) + align_up(si.scr_film, 256) + align_up(si.scr_col, 256) +
+               align_up(si.scr_small, 256) + 5 * 256;
+    tr->shapes[key] = si;
+    *out = si;
+    return CCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
+{
+    if (!cfg || !out) return tfail(CCN_EINVAL, "null argument");
+    if (cfg->n_mult <= 0 || cfg->n_mult > CCN_MAX_MULT || cfg->base <= 0 || cfg->time_dim <= 0 || cfg->z_dim <= 0 || cfg->img_ch <= 0 || cfg->img_ch > 3)
+        return tfail(CCN_EINVAL, "bad config");
+    if (cfg->dtype != CCN_DTYPE_F32 && cfg->dtype != CCN_DTYPE_BF16) return tfail(CCN_EINVAL, "bad dtype");
+    if (cfg->base % 8) return tfail(CCN_EINVAL, "training path needs base % 8 == 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tfail(CCN_EHIP, "no HIP device: libccn_hip.so has no CPU fallback");
+    ccn_trainer_s* tr = new ccn_trainer_s();
+    tr->cfg = *cfg;
+    tr->elem = cfg->dtype == CCN_DTYPE_BF16 ? 2 : 4;
+    tr->G = cfg->groups > 0 ? cfg->groups : 8;
+    build_arch(tr);
+    std::string err;
+    bool good = true;
+    good = good && setup_conv(tr, tr->stem, err) && setup_conv(tr, tr->head, err);
+    for (TRes& r : tr->res) good = good && setup_conv(tr, r.c1, err) && setup_conv(tr, r.c2, err);
+    for (TConvW& w : tr->downs) good = good && setup_conv(tr, w, err);
+    for (TConvW& w : tr->ups) good = good && setup_conv(tr, w, err);
+    int maxc = cfg->base;
+    for (const TRes& r : tr->res) if (r.C > maxc) maxc = r.C;
+    void* zb = nullptr;
+    good = good && alloc_dev(tr, (size_t)(maxc + 256) * 4, &zb, err);
+    if (good && hipMemset(zb, 0, (size_t)(maxc + 256) * 4) != hipSuccess) { good = false; err = "hipMemset failed"; }
+    if (good && (conv_prepare() != hipSuccess || wgrad_prepare() != hipSuccess)) { good = false; err = "kernel attribute setup failed"; }
+    if (!good) { ccn_train_destroy(tr); return tfail(CCN_EHIP, err); }
+    tr->zero_bias = (float*)zb;
+    *out = tr;
+    return CCN_OK;
+}
+
+int ccn_train_destroy(ccn_trainer_t tr)
+{
+    if (!tr) return CCN_OK;
+    for (void* p : tr->allocs) (void)hipFree(p);
+    delete tr;
+    return CCN_OK;
+}
+
+int ccn_train_num_params(ccn_trainer_t tr, int32_t* n, int64_t* total_floats)
+{
+    if (!tr || !n) return tfail(CCN_EINVAL, "null argument");
+    *n = (int32_t)tr->params.size();
+    if (total_floats) *total_floats = (int64_t)tr->total;
+    return CCN_OK;
+}
+
+int ccn_train_param_info(ccn_trainer_t tr, int32_t i, const char** name, int64_t shape[4], int32_t* ndim, int64_t* offset)
+{
+    if (!tr || i < 0 || i >= (int32_t)tr->params.size()) return tfail(CCN_EINVAL, "parameter index out of range");
+    const PInfo& p = tr->params[i];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int32_t)p.shape.size();
+    if (shape) for (size_t k = 0; k < p.shape.size() && k < 4; ++k) shape[k] = p.shape[k];
+    if (offset) *offset = (int64_t)p.off;
+    return CCN_OK;
+}
+
+int ccn_train_workspace_bytes(ccn_trainer_t tr, int32_t B, int32_t H, int32_t W, size_t* bytes)
+{
+    if (!tr || !bytes) return tfail(CCN_EINVAL, "null argument");
+    ShapeInfo si;
+    const int rc = shape_info(tr, B, H, W, &si);
+    if (rc) return rc;
+    *bytes = si.total;
+    return CCN_OK;
+}
+
+int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_t_dev, const float* z_dev, const int64_t* t_dev, float* eps_dev,
+                      int32_t B, int32_t H, int32_t W, void* workspace_dev, size_t workspace_bytes, void* stream)
+{
+    if (!tr || !params_dev || !x_t_dev || !z_dev || !t_dev || !eps_dev) return tfail(CCN_EINVAL, "null argument");
+    ShapeInfo si;
+    int rc = shape_info(tr, B, H, W, &si);
+    if (rc) return rc;
+    if (!workspace_dev || ((uintptr_t)workspace_dev & 255)) return tfail(CCN_EWORKSPACE, "workspace must be non-null and 256-byte aligned");
+    if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(si.total));
+    Walk w(tr, B, H, W, workspace_dev, true, (hipStream_t)stream, params_dev, nullptr);
+    w.place_scratch(si);
+    if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) return tfail(CCN_EHIP, w.err);
+    tr->fB = B; tr->fH = H; tr->fW = W; tr->fws = workspace_dev; tr->fx = x_t_dev;
+    return CCN_OK;
+}
+
+int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_dev, const float* x_t_dev, const float* z_dev, const float* d_eps_dev,
+                       int32_t B, int32_t H, int32_t W, void* workspace_dev, size_t workspace_bytes, void* stream)
+{
+    if (!tr || !params_dev || !grads_dev || !x_t_dev || !z_dev || !d_eps_dev) return tfail(CCN_EINVAL, "null argument");
+    if (tr->fB != B || tr->fH != H || tr->fW != W || tr->fws != workspace_dev)
+        return tfail(CCN_ESTATE, "ccn_train_backward must follow ccn_train_forward with the same shape and workspace");
+    ShapeInfo si;
+    int rc = shape_info(tr, B, H, W, &si);
+    if (rc) return rc;
+    if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small");
+    Walk w(tr, B, H, W, workspace_dev, false, (hipStream_t)stream, params_dev, grads_dev);
+    w.place_scratch(si);
+    if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) return tfail(CCN_EHIP, w.err);
+    w.launch = true;
+    if (!w.backward(x_t_dev, z_dev, d_eps_dev)) return tfail(CCN_EHIP, w.err);
+    return CCN_OK;
+}
+
+int ccn_mse_loss_grad(const float* eps_dev, const float* target_dev, int64_t n, float* loss_dev, float* d_eps_dev, float* scratch_dev, void* stream)
+{
+    if (!eps_dev || !target_dev || !loss_dev || !scratch_dev || n <= 0) return tfail(CCN_EINVAL, "bad argument");
+    if (launch_mse_loss_grad(eps_dev, target_dev, n, loss_dev, d_eps_dev, scratch_dev, (hipStream_t)stream) != hipSuccess) return tfail(CCN_EHIP, "mse launch failed");
+    return CCN_OK;
+}
+
+int ccn_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, void* stream)
+{
+    if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || n <= 0 || step <= 0) return tfail(CCN_EINVAL, "bad argument");
+    if (launch_adamw(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream) != hipSuccess)
+        return tfail(CCN_EHIP, "adamw launch failed");
+    return CCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,761 @@
+// gfx950 kernels of the training step (train/diffusion_train.py:119-124,137-140): the backward pass of CLIPCondUNet.forward.
+//
+// The data gradients of the convolutions are convolutions again and run on the forward implicit-GEMM kernels with
+// re-packed weights (pack_w_kernel): 3x3 s1 -> 3x3 s1 with flipped taps; 3x3 s2 -> the ConvTranspose kernel with a
+// zero-padded 4x4 kernel; ConvTranspose 4x4 s2 -> the stride-2 kernel run with 16 taps.  New here:
+//   wgrad_kernel         dW[tap][co][ci] = sum over pixels dY[p][co] * act(GN(x))[p + d_tap][ci]: the contraction runs over
+//                        PIXELS, so with channel-contiguous (NHWC) tiles in LDS each lane of v_mfma_f32_32x32x2_f32 reads one
+//                        float per operand (lane = channel, k = pixel) -- conflict-free without any transpose.  GroupNorm+SiLU
+//                        of the forward input is redone while staging (the activated tensor is never stored).  Pixel tiles are
+//                        split over workgroups; partial sums go to scratch and are reduced in a fixed order (deterministic).
+//   gn_bwd_*             GroupNorm (+SiLU) backward in two HBM passes: per-channel sums, then the apply pass, which also folds
+//                        the residual-gradient add and the FiLM backward (scale by 1+s, sums for d scale / d shift).
+//   wgrad_small_kernel   stem / head weight gradients (3 image channels x 9 taps against C channels).
+//   tlinear_*            conditioning MLP / FiLM linears, fp32.
+//   adamw_kernel, mse_loss_grad
+#include "ccn_device.h"
+#include "ccn_train.h"
+
+namespace ccn {
+
+namespace {
+template <typename T> __device__ __forceinline__ T to_elem(float v);
+template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 to_elem<__bf16>(float v) { return (__bf16)v; }
+template <typename T> __device__ __forceinline__ float from_elem(T v) { return (float)v; }
+
+// d silu(y) / dy
+template <typename T> __device__ __forceinline__ float dsilu(float y);
+template <> __device__ __forceinline__ float dsilu<float>(float y) { const float sg = 1.0f / (1.0f + expf(-y)); return sg * (1.0f + y * (1.0f - sg)); }
+template <> __device__ __forceinline__ float dsilu<__bf16>(float y) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y)); return sg * (1.0f + y * (1.0f - sg)); }
+
+template <typename T> struct Chunk {                     // one pixel's channel slice: EPC8 = 8 consecutive channels
+    static constexpr int E = 8;
+    static __device__ __forceinline__ void load(const T* p, float* v);
+    static __device__ __forceinline__ void store(T* p, const float* v);
+};
+template <> __device__ __forceinline__ void Chunk<float>::load(const float* p, float* v) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void Chunk<float>::store(float* p, const float* v) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void Chunk<__bf16>::load(const __bf16* p, float* v) { Vec16<__bf16>::unpack(*(const u32x4*)p, v); }
+template <> __device__ __forceinline__ void Chunk<__bf16>::store(__bf16* p, const float* v) { *(u32x4*)p = Vec16<__bf16>::pack(v); }
+
+// scale / shift of channel c of one sample from the pair-interleaved table (see GnCoef)
+__device__ __forceinline__ void ab_of(const float* abf, int c, float& a, float& cc) { a = abf[4 * (c >> 1) + (c & 1)]; cc = abf[4 * (c >> 1) + 2 + (c & 1)]; }
+}  // namespace
+
+// ---- weight repacking --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_w_kernel(const float* __restrict__ w, T* __restrict__ dst, int mode, int O, int I, int taps, int Np, int Kp)
+{
+    const size_t total = (size_t)taps * Np * Kp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % Kp), n = (int)((idx / Kp) % Np), t = (int)(idx / ((size_t)Kp * Np));
+        float v = 0.f;
+        switch (mode) {
+            case PK_CONV3: if (n < O && k < I) v = w[((size_t)n * I + k) * 9 + t]; break;
+            case PK_CONVT: if (n < O && k < I) v = w[((size_t)k * O + n) * 16 + t]; break;
+            case PK_DG3S1: if (n < I && k < O) v = w[((size_t)k * I + n) * 9 + (8 - t)]; break;
+            case PK_DG3S2: { const int ky = t >> 2, kx = t & 3; if (n < I && k < O && ky < 3 && kx < 3) v = w[((size_t)k * I + n) * 9 + ky * 3 + kx]; break; }
+            case PK_DGT: if (n < I && k < O) v = w[((size_t)n * O + k) * 16 + t]; break;
+            case PK_STEM: if (n < O && k < I * 9) v = w[(size_t)n * I * 9 + k]; break;
+            case PK_HEAD_DG: if (n < I && k < O * 9) { const int co = k / 9, tp = k - co * 9; v = w[((size_t)co * I + n) * 9 + (8 - tp)]; } break;
+        }
+        dst[idx] = to_elem<T>(v);
+    }
+}
+hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s)
+{
+    const size_t total = (size_t)taps * Np * Kp;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == 0) hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid ? grid : 1), dim3(256), 0, s, w, (float*)dst, mode, O, I, taps, Np, Kp);
+    else hipLaunchKernelGGL(pack_w_kernel<__bf16>, dim3(grid ? grid : 1), dim3(256), 0, s, w, (__bf16*)dst, mode, O, I, taps, Np, Kp);
+    return hipGetLastError();
+}
+
+// ---- GroupNorm statistics ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float2* __restrict__ part, int G, int n_sp, int n_nt, int bn, int cpg, int C,
+                                                        double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float2* __restrict__ ab, float2* __restrict__ stats)
+{
+    __shared__ double red[4][2];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jlo = (g * cpg) / bn, jhi = ((g + 1) * cpg - 1) / bn, nj = jhi - jlo + 1, ne = n_sp * nj;
+    const float2* base = part + (size_t)(b * G + g) * n_sp * n_nt;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = tid; e < ne; e += 256) {
+        const int sp = e / nj, j = jlo + (e - sp * nj);
+        const float2 v = base[(size_t)sp * n_nt + j];
+        s1 += (double)v.x; s2 += (double)v.y;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
+    __syncthreads();
+    s1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    s2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    if (tid == 0) stats[bg] = make_float2((float)mean, (float)rstd);
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
+        const double sc = (double)gamma[c] * rstd;
+        float* const row = (float*)(ab + (size_t)b * C) + 4 * (c >> 1) + (c & 1);
+        row[0] = (float)sc; row[2] = (float)((double)beta[c] - mean * sc);
+    }
+}
+hipError_t launch_gn_stats(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C, double count, const float* gamma,
+                           const float* beta, float eps, float2* ab, float2* stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, part, G, n_sp, n_nt, bn, cpg, C, count, gamma, beta, eps, ab, stats);
+    return hipGetLastError();
+}
+
+// ---- GroupNorm (+SiLU) backward -----------------------------------------------------------------------------------------
+// Thread -> a fixed slice of 8 channels (coefficients in registers) x a strided set of the block's pixels.
+GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
+{
+    (void)dtype;
+    GnBwdGeom g{};
+    const int nsl = C / 8;
+    int nslb = nsl <= 256 ? nsl : 256;
+    while (nsl % nslb) --nslb;                                   // largest divisor of nsl that fits a workgroup
+    g.nslb = nslb; g.zblocks = nsl / nslb; g.pstep = 256 / nslb;
+    g.ppb = g.pstep * 32;                                        // pixels per workgroup
+    g.nblk = (HW + g.ppb - 1) / g.ppb;
+    return g;
+}
+
+// block-level reduction of per-thread (s1[8], s2[8]) over the pixel lanes; result valid in threads with pp == 0
+__device__ __forceinline__ void block_reduce16(float* sh, int tid, int sl, int pp, int nslb, int pstep, float* s1, float* s2)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[tid * 17 + e] = s1[e]; sh[tid * 17 + 8 + e] = s2[e]; }
+    __syncthreads();
+    if (pp == 0) {
+        for (int q = 1; q < pstep; ++q) {
+            const float* o = sh + (q * nslb + sl) * 17;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += o[e]; s2[e] += o[8 + e]; }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dA, const float2* __restrict__ ab,
+                                                             const float2* __restrict__ stats, float2* __restrict__ part, int HW, int C,
+                                                             int cpg, int G, int silu, int nslb, int pstep, int ppb, int nblk)
+{
+    __shared__ float sh[256 * 17];
+    const int tid = threadIdx.x, b = blockIdx.y, blk = blockIdx.x;
+    const int sl = tid % nslb, pp = tid / nslb;
+    const bool act = pp < pstep;
+    const int ch0 = (blockIdx.z * nslb + sl) * 8;
+    float a[8], c[8], mu[8], rs[8], s1[8], s2[8];
+    const float* abf = (const float*)(ab + (size_t)b * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ab_of(abf, ch0 + e, a[e], c[e]);
+        const float2 st = stats[b * G + (ch0 + e) / cpg];
+        mu[e] = st.x; rs[e] = st.y; s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const int pend = min(HW, (blk + 1) * ppb);
+    if (act)
+        for (int p = blk * ppb + pp; p < pend; p += pstep) {
+            float xv[8], dv[8];
+            const size_t off = ((size_t)b * HW + p) * C + ch0;
+            Chunk<T>::load(x + off, xv); Chunk<T>::load(dA + off, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float da = dv[e];
+                if (silu) da *= dsilu<T>(fmaf(xv[e], a[e], c[e]));
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                s1[e] += da; s2[e] = fmaf(da, xh, s2[e]);
+            }
+        }
+    block_reduce16(sh, tid, sl, pp, nslb, pstep, s1, s2);
+    if (pp == 0) {
+        float2* o = part + ((size_t)b * nblk + blk) * C + ch0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = make_float2(s1[e], s2[e]);
+    }
+}
+hipError_t launch_gn_bwd_reduce(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, float2* part, int B, int HW,
+                                int C, int cpg, int G, int silu, hipStream_t s)
+{
+    if (C % 8) return hipErrorInvalidValue;
+    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const dim3 grid(g.nblk, B, g.zblocks);
+    if (dtype == 0) hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dA, ab, stats, part, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
+    else hipLaunchKernelGGL(gn_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dA, ab, stats, part, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, int cpg, int G, double count,
+                                                               const float* __restrict__ gamma, float2* __restrict__ gstat,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ double red[4][2];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double m1 = 0.0, m2 = 0.0;
+    for (int c = g * cpg + wave; c < (g + 1) * cpg; c += 4) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < nblk; k += 64) { const float2 v = part[((size_t)b * nblk + k) * C + c]; s1 += (double)v.x; s2 += (double)v.y; }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
+        if (lane == 0) { atomicAdd(dgamma + c, (float)s2); atomicAdd(dbeta + c, (float)s1); }
+        m1 += (double)gamma[c] * s1; m2 += (double)gamma[c] * s2;
+    }
+    if (lane == 0) { red[wave][0] = m1; red[wave][1] = m2; }
+    __syncthreads();
+    if (tid == 0) {
+        m1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        m2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        gstat[bg] = make_float2((float)(m1 / count), (float)(m2 / count));
+    }
+}
+hipError_t launch_gn_bwd_finalize(const float2* part, int nblk, int B, int C, int cpg, int G, double count, const float* gamma, float2* gstat,
+                                  float* dgamma, float* dbeta, hipStream_t s)
+{
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G), dim3(256), 0, s, part, nblk, C, cpg, G, count, gamma, gstat, dgamma, dbeta);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* dA, const float2* __restrict__ ab,
+                                                            const float2* __restrict__ stats, const float2* __restrict__ gstat,
+                                                            const T* __restrict__ addend, T* out, const float* __restrict__ film,
+                                                            int film_bstride, float2* __restrict__ fpart, int HW, int C, int cpg, int G,
+                                                            int silu, int nslb, int pstep, int ppb, int nblk)
+{
+    __shared__ float sh[256 * 17];
+    const int tid = threadIdx.x, b = blockIdx.y, blk = blockIdx.x;
+    const int sl = tid % nslb, pp = tid / nslb;
+    const bool act = pp < pstep;
+    const int ch0 = (blockIdx.z * nslb + sl) * 8;
+    float a[8], c[8], mu[8], rs[8], m1[8], m2[8], fs[8], s1[8], s2[8];
+    const float* abf = (const float*)(ab + (size_t)b * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ab_of(abf, ch0 + e, a[e], c[e]);
+        const int g = (ch0 + e) / cpg;
+        const float2 st = stats[b * G + g], gs = gstat[b * G + g];
+        mu[e] = st.x; rs[e] = st.y; m1[e] = gs.x; m2[e] = gs.y;
+        fs[e] = film ? 1.0f + film[(size_t)b * film_bstride + ch0 + e] : 1.0f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const int pend = min(HW, (blk + 1) * ppb);
+    if (act)
+        for (int p = blk * ppb + pp; p < pend; p += pstep) {
+            float xv[8], dv[8], rv[8], ov[8];
+            const size_t off = ((size_t)b * HW + p) * C + ch0;
+            Chunk<T>::load(x + off, xv); Chunk<T>::load(dA + off, dv);
+            if (addend) Chunk<T>::load(addend + off, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float da = dv[e];
+                if (silu) da *= dsilu<T>(fmaf(xv[e], a[e], c[e]));
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                const float dx = a[e] * da - rs[e] * fmaf(xh, m2[e], m1[e]);
+                s1[e] += dx; s2[e] = fmaf(dx, xv[e], s2[e]);
+                float o = dx * fs[e];
+                if (addend) o += rv[e];
+                ov[e] = o;
+            }
+            Chunk<T>::store(out + off, ov);
+        }
+    if (!fpart) return;
+    block_reduce16(sh, tid, sl, pp, nslb, pstep, s1, s2);
+    if (pp == 0) {
+        float2* o = fpart + ((size_t)b * nblk + blk) * C + ch0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = make_float2(s1[e], s2[e]);
+    }
+}
+hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, const float2* gstat,
+                               const void* addend, void* out, const float* film, int film_bstride, float2* fpart, int B, int HW, int C,
+                               int cpg, int G, int silu, hipStream_t s)
+{
+    if (C % 8) return hipErrorInvalidValue;
+    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const dim3 grid(g.nblk, B, g.zblocks);
+    if (dtype == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dA, ab, stats, gstat, (const float*)addend, (float*)out, film, film_bstride, fpart, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
+    else hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dA, ab, stats, gstat, (const __bf16*)addend, (__bf16*)out, film, film_bstride, fpart, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
+    return hipGetLastError();
+}
+
+// d scale[b][c] = sum dF * y1, y1 = (F - shift) / (1 + scale); d shift[b][c] = sum dF   (F = y1 (1 + scale) + shift is what the
+// forward stored; a block whose 1 + scale is exactly zero has lost y1 and gets d scale = 0)
+__global__ void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int nblk, const float* __restrict__ film, int film_bstride,
+                                         float* __restrict__ dfilm, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) { const float2 v = fpart[((size_t)b * nblk + k) * C + c]; s1 += (double)v.x; s2 += (double)v.y; }
+    const float sc = 1.0f + film[(size_t)b * film_bstride + c], sft = film[(size_t)b * film_bstride + C + c];
+    dfilm[(size_t)b * film_bstride + c] = sc != 0.f ? (float)((s2 - (double)sft * s1) / (double)sc) : 0.f;
+    dfilm[(size_t)b * film_bstride + C + c] = (float)s1;
+}
+hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, int B, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(film_bwd_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, fpart, nblk, film, film_bstride, dfilm, C);
+    return hipGetLastError();
+}
+
+// ---- bias gradients -------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ scratch, int HW, int C, int nslb, int pstep,
+                                                      int ppb, int nblk)
+{
+    __shared__ float sh[256 * 17];
+    const int tid = threadIdx.x, b = blockIdx.y, blk = blockIdx.x;
+    const int sl = tid % nslb, pp = tid / nslb;
+    const int ch0 = (blockIdx.z * nslb + sl) * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const int pend = min(HW, (blk + 1) * ppb);
+    if (pp < pstep)
+        for (int p = blk * ppb + pp; p < pend; p += pstep) {
+            float dv[8];
+            Chunk<T>::load(dy + ((size_t)b * HW + p) * C + ch0, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1[e] += dv[e];
+        }
+    block_reduce16(sh, tid, sl, pp, nslb, pstep, s1, s2);
+    if (pp == 0) {
+        float* o = scratch + ((size_t)b * nblk + blk) * C + ch0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = s1[e];
+    }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ scratch, int rows, int C, float* __restrict__ db)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < rows; ++k) s += (double)scratch[(size_t)k * C + c];
+    db[c] += (float)s;
+}
+hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s)
+{
+    if (C % 8) return hipErrorInvalidValue;
+    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const dim3 grid(g.nblk, B, g.zblocks);
+    if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
+    else hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, B * g.nblk, C, db);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void nchw_chansum_kernel(const float* __restrict__ x, float* __restrict__ db, int B, int C, int64_t hw)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* p = x + ((size_t)b * C + c) * hw;
+        for (int64_t i = tid; i < hw; i += 256) s += (double)p[i];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) db[c] += (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+hipError_t launch_nchw_chansum(const float* x, float* db, int B, int C, int64_t hw, hipStream_t s)
+{
+    hipLaunchKernelGGL(nchw_chansum_kernel, dim3(C), dim3(256), 0, s, x, db, B, C, hw);
+    return hipGetLastError();
+}
+
+// ---- weight gradients -------------------------------------------------------------------------------------------------------
+// Workgroup = (Cout tile of 32*WN, Cin tile of 32*WK, parity, pixel split); 4 waves, each a 32 x 32 (co, ci) tile for all NTAPS
+// taps (16 accumulator registers per tap).  Per pixel tile (4 rows x 32 pixels of the conv's M-space): stage dY [128][NT] and
+// the activated input halo [ROWS][PITCH][KT] as fp32 in LDS, then for every pixel pair one LDS float per operand and one
+// v_mfma_f32_32x32x2_f32 per tap (k = the two pixels).
+template <int IS> struct WgGeom {
+    static constexpr int ROWS = IS * 3 + 3, PITCH = IS == 1 ? 34 : 66;
+};
+template <typename T, int IS, int NTAPS, int WN, int WK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a)
+{
+    constexpr int NT = 32 * WN, KT = 32 * WK, EPC = Vec16<T>::EPC;
+    constexpr int ROWS = WgGeom<IS>::ROWS, PITCH = WgGeom<IS>::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const As = (float*)smem;                                   // [ROWS*PITCH][KT]
+    float* const Ds = As + ROWS * PITCH * KT;                          // [128][NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wn = wave / WK, wk = wave % WK;
+    const int n_kt = (a.Cin + KT - 1) / KT, n_nt = (a.Cout + NT - 1) / NT;
+    int bid = blockIdx.x;
+    const int kt = bid % n_kt; bid /= n_kt;
+    const int nt = bid % n_nt; bid /= n_nt;
+    const int par = bid % a.npar; const int split = bid / a.npar;
+    const int k0 = kt * KT, n0 = nt * NT, py = par >> 1, px = par & 1, par_off = par * 4;
+
+    int toff[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) toff[t] = ((a.tapinfo_dy(par_off + t) + 1) * PITCH + a.tapinfo_dx(par_off + t) + 1) * KT;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const int tiles = a.B * a.n_ty * a.n_tx;
+    for (int tile = split; tile < tiles; tile += a.nsplit) {
+        const int tx = tile % a.n_tx, ty = (tile / a.n_tx) % a.n_ty, b = tile / (a.n_tx * a.n_ty);
+        const int my0 = ty * 4, mx0 = tx * 32;
+        __syncthreads();                                            // previous tile's reads are done
+        {   // activated input halo
+            constexpr int CH = KT / EPC;                              // 16-byte chunks per pixel
+            const int ck = tid % CH, cbase = k0 + ck * EPC;
+            const bool cvalid = cbase < a.Cin;
+            GnCoef<T> gk;
+            gk.load(a.gn_ab + (size_t)b * a.Cin + (cvalid ? cbase : 0), a.gn_ab != nullptr && cvalid);
+            const int iy0 = IS * my0 - 1, ix0 = IS * mx0 - 1;
+            for (int pxl = tid / CH; pxl < ROWS * PITCH; pxl += 256 / CH) {
+                const int hy = pxl / PITCH, hx = pxl - hy * PITCH, iy = iy0 + hy, ix = ix0 + hx;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                    v = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
+                    if (a.gn_ab) v = gk.template apply<true>(v);
+                }
+                float f[EPC];
+                Vec16<T>::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) *(f32x4*)(As + pxl * KT + ck * EPC + e) = f32x4{f[e], f[e + 1], f[e + 2], f[e + 3]};
+            }
+        }
+        {   // output gradient tile
+            constexpr int CH = NT / EPC;
+            const int ck = tid % CH, nbase = n0 + ck * EPC;
+            for (int m = tid / CH; m < 128; m += 256 / CH) {
+                const int my = my0 + (m >> 5), mx = mx0 + (m & 31);
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (nbase < a.Cout && my < a.MH && mx < a.MW)
+                    v = *(const u32x4*)((const T*)a.dy + ((size_t)(b * a.Hout + my * a.OS + py) * a.Wout + mx * a.OS + px) * a.Cout + nbase);
+                float f[EPC];
+                Vec16<T>::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) *(f32x4*)(Ds + m * NT + ck * EPC + e) = f32x4{f[e], f[e + 1], f[e + 2], f[e + 3]};
+            }
+        }
+        __syncthreads();
+        const float* const Aw = As + wk * 32 + r;
+        const float* const Dw = Ds + wn * 32 + r;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll 4
+            for (int jp = 0; jp < 16; ++jp) {
+                const int j = 2 * jp + h;
+                const float dv = Dw[(i * 32 + j) * NT];
+                const float* ap = Aw + (IS * i * PITCH + IS * j) * KT;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, ap[toff[t]], acc[t], 0, 0, 0);
+            }
+    }
+    // D: lane r = column (ci), register q = row (co) (q & 3) + 8 (q >> 2) + 4 h
+    const int k = k0 + wk * 32 + r;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int wt = a.tapinfo_w(par_off + t);
+        float* const o = a.part + ((size_t)split * a.taps_w + wt) * a.Cout * a.Cin;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n0 + wn * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (n < a.Cout && k < a.Cin) o[(size_t)n * a.Cin + k] = acc[t][q];
+        }
+    }
+}
+
+template <int IS, int WN, int WK> static constexpr size_t wgrad_lds() { return (size_t)(WgGeom<IS>::ROWS * WgGeom<IS>::PITCH * 32 * WK + 128 * 32 * WN) * 4; }
+typedef void (*wgrad_fn_t)(const WgArgs);
+static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt)
+{
+    switch (kind) {
+        case KIND_C3S2: *lds = wgrad_lds<2, 4, 1>(); *nt = 128; *kt = 32;
+            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 2, 9, 4, 1> : (wgrad_fn_t)wgrad_kernel<__bf16, 2, 9, 4, 1>;
+        case KIND_CT4: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64;
+            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 1, 4, 2, 2> : (wgrad_fn_t)wgrad_kernel<__bf16, 1, 4, 2, 2>;
+        default: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64;
+            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 1, 9, 2, 2> : (wgrad_fn_t)wgrad_kernel<__bf16, 1, 9, 2, 2>;
+    }
+}
+hipError_t wgrad_prepare()
+{
+    static const int kinds[] = {KIND_C3S1, KIND_C3S2, KIND_CT4};
+    for (int dt = 0; dt < 2; ++dt)
+        for (int kind : kinds) {
+            size_t lds; int nt, kt;
+            const wgrad_fn_t fn = wgrad_pick(dt, kind, &lds, &nt, &kt);
+            hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+int wgrad_nsplit(int kind, int B, int MH, int MW, int Cin, int Cout)
+{
+    size_t lds; int nt, kt;
+    (void)wgrad_pick(0, kind, &lds, &nt, &kt);
+    const int npar = kind == KIND_CT4 ? 4 : 1;
+    const int tiles = B * ((MH + 3) / 4) * ((MW + 31) / 32);
+    const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
+    int ns = (768 + groups - 1) / groups;                         // ~3 workgroups per CU
+    if (ns > tiles) ns = tiles;
+    return ns < 1 ? 1 : ns;
+}
+hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
+{
+    size_t lds; int nt, kt;
+    const wgrad_fn_t fn = wgrad_pick(dtype, kind, &lds, &nt, &kt);
+    const int epc = dtype == 0 ? 4 : 8;
+    if (a.Cin % epc || a.Cout % epc) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(((a.Cin + kt - 1) / kt) * ((a.Cout + nt - 1) / nt) * a.npar * a.nsplit);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int taps, int O, int I, int transposed, float* __restrict__ grad)
+{
+    const size_t per = (size_t)taps * O * I;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I), o = (int)((idx / I) % O), t = (int)(idx / ((size_t)I * O));
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * per + idx];
+        const size_t dst = transposed ? ((size_t)i * O + o) * taps + t : ((size_t)o * I + i) * taps + t;
+        grad[dst] += s;
+    }
+}
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int transposed, float* grad, hipStream_t s)
+{
+    const size_t per = (size_t)taps * O * I;
+    const unsigned grid = (unsigned)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, taps, O, I, transposed, grad);
+    return hipGetLastError();
+}
+
+// stem / head: block = (8 image rows, sample, channel block); thread -> (channel, pixel lane), 27 accumulators (img_ch <= 3)
+constexpr int WS_ROWS = 8;
+int wsmall_blocks(int H) { return (H + WS_ROWS - 1) / WS_ROWS; }
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ xn, const float2* __restrict__ gn_ab, const float* __restrict__ img,
+                                                           int img_ch, int sgn, float* __restrict__ part, int H, int W, int C, int cb)
+{
+    extern __shared__ float simg[];                                  // [img_ch][3][W + 2], then the reduction buffer
+    const int tid = threadIdx.x, b = blockIdx.y, rb = blockIdx.x;
+    const int cl = tid % cb, xl = tid / cb, lanes = 256 / cb;
+    const int c = blockIdx.z * cb + cl;
+    const bool act = xl < lanes && c < C;
+    float a = 1.f, cc = 0.f;
+    if (gn_ab && c < C) ab_of((const float*)(gn_ab + (size_t)b * C), c, a, cc);
+    float acc[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) acc[j] = 0.f;
+    const int WP = W + 2;
+    for (int y = rb * WS_ROWS; y < min(H, (rb + 1) * WS_ROWS); ++y) {
+        __syncthreads();
+        for (int i = tid; i < img_ch * 3 * WP; i += 256) {
+            const int xx = i % WP - 1, rr = (i / WP) % 3, ch = i / (3 * WP);
+            const int yy = y + rr - 1;
+            simg[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)(b * img_ch + ch) * H + yy) * W + xx] : 0.f;
+        }
+        __syncthreads();
+        if (act)
+            for (int x = xl; x < W; x += lanes) {
+                float v = from_elem<T>(xn[((size_t)(b * H + y) * W + x) * C + c]);
+                if (gn_ab) v = fmaf(v, a, cc);
+#pragma unroll
+                for (int j = 0; j < 27; ++j) {
+                    const int ch = j / 9, t = j % 9, dy = t / 3 - 1, dx = t % 3 - 1;
+                    if (ch < img_ch) acc[j] = fmaf(v, simg[(ch * 3 + 1 + sgn * dy) * WP + x + 1 + sgn * dx], acc[j]);
+                }
+            }
+    }
+    __syncthreads();
+    float* red = simg;                                               // [256][27]
+#pragma unroll
+    for (int j = 0; j < 27; ++j) red[tid * 27 + j] = acc[j];
+    __syncthreads();
+    if (xl == 0 && c < C) {
+        for (int q = 1; q < lanes; ++q)
+#pragma unroll
+            for (int j = 0; j < 27; ++j) acc[j] += red[(q * cb + cl) * 27 + j];
+        float* o = part + (((size_t)b * gridDim.x + rb) * C + c) * 27;
+#pragma unroll
+        for (int j = 0; j < 27; ++j) o[j] = acc[j];
+    }
+}
+hipError_t launch_wgrad_small(int dtype, const void* xn, const float2* gn_ab, const float* img, int img_ch, int sgn, float* part, int B, int H,
+                              int W, int C, hipStream_t s)
+{
+    if (img_ch > 3 || W > 2048) return hipErrorInvalidValue;
+    const int cb = C < 256 ? C : 256;
+    const dim3 grid(wsmall_blocks(H), B, (C + cb - 1) / cb);
+    size_t lds = (size_t)img_ch * 3 * (W + 2) * 4;
+    if (lds < 256 * 27 * 4) lds = 256 * 27 * 4;
+    if (dtype == 0) hipLaunchKernelGGL(wgrad_small_kernel<float>, grid, dim3(256), lds, s, (const float*)xn, gn_ab, img, img_ch, sgn, part, H, W, C, cb);
+    else hipLaunchKernelGGL(wgrad_small_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)xn, gn_ab, img, img_ch, sgn, part, H, W, C, cb);
+    return hipGetLastError();
+}
+// part [nblk][C][27] -> stem: grad[(c*img_ch + ch)*9 + t]; head: grad[(ch*C + c)*9 + t]
+__global__ void wsmall_reduce_kernel(const float* __restrict__ part, int nblk, int C, int img_ch, int head, float* __restrict__ grad)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * 27) return;
+    const int c = idx / 27, j = idx % 27, ch = j / 9, t = j % 9;
+    if (ch >= img_ch) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)part[(size_t)k * C * 27 + idx];
+    grad[head ? ((size_t)ch * C + c) * 9 + t : ((size_t)c * img_ch + ch) * 9 + t] += (float)s;
+}
+hipError_t launch_wsmall_reduce(const float* part, int nblk, int C, int img_ch, int head, float* grad, hipStream_t s)
+{
+    hipLaunchKernelGGL(wsmall_reduce_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, s, part, nblk, C, img_ch, head, grad);
+    return hipGetLastError();
+}
+
+// ---- small fp32 linears ---------------------------------------------------------------------------------------------------
+// y[r][n] = act(u), u = sum_k x[r][k] W[n][k] + b[n]; one wave per n, lanes stride K (as linear_kernel in ccn_kernels.hip)
+__global__ __launch_bounds__(256) void tlinear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int ldy, float* __restrict__ u, int R, int K, int N, int silu)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const float* wrow = W + (size_t)n * K;
+    for (int rr = 0; rr < R; ++rr) {
+        const float* pa = x + (size_t)rr * ldx;
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(pa[k], wrow[k], acc);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+        if (lane == 0) {
+            float v = acc + (bias ? bias[n] : 0.f);
+            if (u) u[(size_t)rr * ldy + n] = v;
+            if (silu) v = v / (1.0f + expf(-v));
+            y[(size_t)rr * ldy + n] = v;
+        }
+    }
+}
+hipError_t launch_tlinear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, float* u, int R, int K, int N, int silu,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(tlinear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, W, b, y, ldy, u, R, K, N, silu);
+    return hipGetLastError();
+}
+__global__ void tlinear_dw_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                  float* __restrict__ db, int R, int K, int N)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * K) return;
+    const int k = (int)(idx % K), n = (int)(idx / K);
+    float acc = 0.f, sb = 0.f;
+    for (int r = 0; r < R; ++r) { const float d = dy[(size_t)r * lddy + n]; acc = fmaf(d, x[(size_t)r * ldx + k], acc); sb += d; }
+    dW[idx] += acc;
+    if (k == 0 && db) db[n] += sb;
+}
+hipError_t launch_tlinear_dw(const float* dy, int lddy, const float* x, int ldx, float* dW, float* db, int R, int K, int N, hipStream_t s)
+{
+    hipLaunchKernelGGL(tlinear_dw_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, dy, lddy, x, ldx, dW, db, R, K, N);
+    return hipGetLastError();
+}
+__global__ void tlinear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ W, float* __restrict__ dx, int lddx, int R,
+                                  int K, int N, int accumulate)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(dy[(size_t)r * lddy + n], W[(size_t)n * K + k], acc);
+    float* o = dx + (size_t)r * lddx + k;
+    *o = accumulate ? *o + acc : acc;
+}
+hipError_t launch_tlinear_dx(const float* dy, int lddy, const float* W, float* dx, int lddx, int R, int K, int N, int accumulate, hipStream_t s)
+{
+    hipLaunchKernelGGL(tlinear_dx_kernel, dim3((K + 255) / 256, R), dim3(256), 0, s, dy, lddy, W, dx, lddx, R, K, N, accumulate);
+    return hipGetLastError();
+}
+__global__ void silu_bwd_kernel(float* __restrict__ du, const float* __restrict__ dy, const float* __restrict__ u, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) du[i] = dy[i] * dsilu<float>(u[i]);
+}
+hipError_t launch_silu_bwd(float* du, const float* dy, const float* u, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, du, dy, u, n);
+    return hipGetLastError();
+}
+__global__ void add2_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+hipError_t launch_add2(float* y, const float* a, const float* b, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, a, b, n);
+    return hipGetLastError();
+}
+
+// ---- loss and optimiser ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ eps, const float* __restrict__ target, int64_t n, float inv_n,
+                                                           float* __restrict__ d_eps, float* __restrict__ scratch)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = eps[i] - target[i];
+        s += (double)d * (double)d;
+        if (d_eps) d_eps[i] = 2.0f * d * inv_n;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void mse_final_kernel(const float* __restrict__ scratch, int nb, double inv_n, float* __restrict__ loss)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += (double)scratch[i];
+    *loss = (float)(s * inv_n);
+}
+hipError_t launch_mse_loss_grad(const float* eps, const float* target, int64_t n, float* loss, float* d_eps, float* scratch, hipStream_t s)
+{
+    const int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, eps, target, n, (float)(1.0 / (double)n), d_eps, scratch);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, scratch, nb, 1.0 / (double)n, loss);
+    return hipGetLastError();
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                             float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                        hipStream_t s)
+{
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    return hipGetLastError();
+}
+
+}  // namespace ccn

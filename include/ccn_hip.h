@@ -153,6 +153,51 @@ int ccn_profile_read(ccn_handle_t h, const char** names, float* ms, int32_t* cal
  * under this handle's storage dtype. */
 int ccn_algorithmic_work(ccn_handle_t h, int32_t B, int32_t H, int32_t W, double* flops, double* bytes);
 
+/* ---- training step (train/diffusion_train.py:119-124,137-140) --------------------------------- *
+ * The reference trains with `eps_hat = net(x_t, z, t); loss = F.mse_loss(eps_hat, noise); loss.backward(); opt.step()`.
+ * A trainer handle reads the parameters from ONE flat fp32 device buffer owned by the caller (the entries of
+ * CLIPCondUNet.state_dict(), in registration order, each at the offset ccn_train_param_info reports -- a torch caller makes
+ * every nn.Parameter a view into it) and accumulates gradients into a second flat buffer of the same layout.
+ * Arithmetic mode as for inference: CCN_DTYPE_F32 (parity) or CCN_DTYPE_BF16 (activations and conv operands in bf16,
+ * fp32 accumulation, fp32 GroupNorm statistics, fp32 gradients and optimiser state: what torch.autocast(bfloat16) does
+ * at train/diffusion_train.py:121). */
+typedef struct ccn_trainer_s* ccn_trainer_t;
+
+/* net = CLIPCondUNet(...).to(device); net.train() (train/diffusion_train.py:103,109) */
+int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out);
+int ccn_train_destroy(ccn_trainer_t tr);
+
+/* Number of parameters, total floats of the flat buffer; i-th key / shape / offset (in floats) into the flat buffer. */
+int ccn_train_num_params(ccn_trainer_t tr, int32_t* n, int64_t* total_floats);
+int ccn_train_param_info(ccn_trainer_t tr, int32_t i, const char** name, int64_t shape[4], int32_t* ndim, int64_t* offset);
+
+/* Scratch for one forward+backward at this shape (every activation of the forward is kept for the backward). */
+int ccn_train_workspace_bytes(ccn_trainer_t tr, int32_t B, int32_t H, int32_t W, size_t* bytes);
+
+/* eps_hat = net(x_t, z, t) (train/diffusion_train.py:123; models/unet.py:81-106), activations kept in the workspace.
+ * x_t_dev (B,img_ch,H,W) fp32 NCHW; z_dev (B,z_dim); t_dev (B,) int64; eps_dev (B,img_ch,H,W) fp32 NCHW. */
+int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_t_dev, const float* z_dev,
+                      const int64_t* t_dev, float* eps_dev, int32_t B, int32_t H, int32_t W,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The backward pass of that forward (loss.backward(), train/diffusion_train.py:137) for a given d loss / d eps_hat
+ * (B,img_ch,H,W) fp32 NCHW: grads_dev[offset_i ...] += d loss / d param_i for every parameter (the caller zeroes the
+ * buffer when it wants plain gradients, as opt.zero_grad does at :140).  Must follow ccn_train_forward with the same
+ * shape, workspace and x_t_dev / z_dev contents; the parameters must not have changed in between. */
+int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_dev, const float* x_t_dev,
+                       const float* z_dev, const float* d_eps_dev, int32_t B, int32_t H, int32_t W,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* F.mse_loss(eps_hat, noise) (train/diffusion_train.py:124) and its gradient: *loss_dev = mean((eps - target)^2),
+ * d_eps_dev = 2 (eps - target) / n (may be NULL).  scratch_dev: at least 1024 floats. */
+int ccn_mse_loss_grad(const float* eps_dev, const float* target_dev, int64_t n, float* loss_dev, float* d_eps_dev,
+                      float* scratch_dev, void* stream);
+
+/* One torch.optim.AdamW step over a flat buffer (train/diffusion_train.py:105,138): p *= 1 - lr*wd;
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps). step >= 1. */
+int ccn_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
 const char* ccn_last_error(void);
 const char* ccn_version(void);
 

@@ -336,6 +336,26 @@ def test_other_width_base192_two_levels(synth):
     assert torch.isfinite(e16).all() and d < 2e-2, d
 
 
+def test_c4_architecture_four_levels_base192(synth):
+    """BASELINE.json configs[3]'s architecture (base 192, ch_mult (1,2,2,4): widths 192/192/384/768/3072, 815.7 M
+    parameters, four resolution levels, 384 channels per GroupNorm group at the bottom) at a 64 px input so that the
+    oracle finishes in seconds: fp32 mode against the CPU oracle on one sample, bf16 mode against fp32 on the batch."""
+    spec = synth.unet_param_spec(512, 192, (1, 2, 2, 4))
+    assert sum(int(np.prod(s)) for _, s in spec) == 815_721_475        # SURVEY.md section 8 row a1
+    sd = synth.synth_state_dict(spec)
+    B, S = 2, 64
+    g = torch.Generator("cpu").manual_seed(5)
+    x = torch.randn((B, 3, S, S), generator=g); z = torch.from_numpy(synth.synth_z(B)); t = torch.tensor([999, 250])
+    e32 = make_net(sd, 192, (1, 2, 2, 4))(to_dev(x), to_dev(z), to_dev(t))
+    with torch.no_grad():
+        ref = ref_unet.unet_forward(ref_unet.as_torch_sd(sd), x[1:2], z[1:2], t[1:2])
+    assert maxerr(e32[1:2], ref) < TOL_EPS_FP32, maxerr(e32[1:2], ref)
+    e16 = make_net(sd, 192, (1, 2, 2, 4), dtype="bf16")(to_dev(x), to_dev(z), to_dev(t))
+    d = maxerr(e16, e32)
+    print(f"C4 architecture @64px: fp32 vs oracle {maxerr(e32[1:2], ref):.2e}; bf16 vs fp32 {d:.3e}")
+    assert torch.isfinite(e16).all() and d < 2e-2, d
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 72, 104), (8, 40, 48), (5, 136, 200), (2, 264, 136), (16, 128, 128)])
 def test_c2_architecture_odd_shapes(synth, c2_sd, B, H, W):
     """Batch / image sizes that change which kernel takes each layer (tile counts decide between the persistent kernel, its

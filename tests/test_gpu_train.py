@@ -1,0 +1,166 @@
+"""Training step (BASELINE.json configs[4]) on the GPU through the C ABI: loss, every parameter gradient and the AdamW update
+against the CPU oracle (oracle/ref_train.py, pinned to the reference by tests/golden/train_step.npz)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "clip-neural-image-conpression_amd")]
+
+from clip_feature_codec import _native  # noqa: E402
+from clip_feature_codec.models.unet import CLIPCondUNet  # noqa: E402
+from clip_feature_codec.diffusion.scheduler import NoiseScheduler  # noqa: E402
+from clip_feature_codec.train.diffusion_train import FusedAdamW, train_step  # noqa: E402
+from clip_feature_codec.utils import synth  # noqa: E402
+from oracle import ref_unet, ref_train, ref_diffusion  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = np.load(ROOT / "tests" / "golden" / "train_step.npz")
+
+
+def make_net(sd, base, ch_mult, dtype="fp32"):
+    net = CLIPCondUNet(z_dim=512, base=base, ch_mult=ch_mult, dtype=dtype).to(DEV)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.train()
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+def grads_via_autograd(net, x_t, z, t, target):
+    net.zero_grad(set_to_none=True)
+    eps = net(x_t.to(DEV), z.to(DEV), t.to(DEV))
+    loss = F.mse_loss(eps, target.to(DEV))
+    loss.backward()
+    return loss.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}, eps.detach().cpu()
+
+
+def check_grads(got, ref, tol, what):
+    worst = ("", 0.0)
+    for k, g in ref.items():
+        e = rel_err(got[k], g)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < tol, f"{what}: {k} relative max error {e:.3e} (|g|max {float(g.abs().max()):.3e})"
+    print(f"{what}: worst parameter {worst[0]} rel err {worst[1]:.2e}")
+
+
+def test_c1_shape_loss_and_all_gradients_fp32_match_reference_fixture_and_oracle():
+    """The fixture's inputs (base 32, (1,2), 64 px, B=2): loss.backward() through CLIPCondUNet.forward in fp32 mode."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    x0, z, t, noise = (torch.from_numpy(GOLD[k]) for k in ("x0", "z", "t", "noise"))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    assert np.abs(sch.q_sample(x0.to(DEV), t.to(DEV), noise.to(DEV)).cpu().numpy() - GOLD["x_t"]).max() < 1e-6
+    x_t = torch.from_numpy(GOLD["x_t"])
+    net = make_net(sd, 32, (1, 2))
+    loss, grads, eps = grads_via_autograd(net, x_t, z, t, noise)
+    assert abs(float(loss) - float(GOLD["loss"])) < 2e-6
+    rloss, rgrads, reps = ref_train.loss_and_grads(ref_unet.as_torch_sd(sd), x_t, z, t, noise)
+    assert rel_err(eps, reps) < 1e-4
+    check_grads(grads, rgrads, 2e-4, "fp32 C1 shape")
+    for k in GOLD["names"]:                                    # and straight against what the reference produced
+        k = str(k)
+        g = grads[k].flatten()
+        step = max(1, g.numel() // 64)
+        scale = max(float(g.abs().max()), 1e-12)
+        assert np.abs(g[::step][:64].numpy() - GOLD[f"gsample/{k}"]).max() <= 2e-4 * scale + 1e-9, k
+
+
+@pytest.mark.parametrize("base,ch_mult,B,H,W", [(32, (1, 2), 3, 40, 72), (64, (1, 2, 2), 2, 64, 96), (96, (2,), 1, 36, 44)])
+def test_gradients_fp32_other_shapes(base, ch_mult, B, H, W):
+    """Ragged tiles, three levels, channel counts that are not a power of two, batch of one."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, base, ch_mult))
+    g = torch.Generator("cpu").manual_seed(B * 100 + H)
+    x_t = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.randint(0, 1000, (B,), generator=g); target = torch.randn((B, 3, H, W), generator=g)
+    net = make_net(sd, base, ch_mult)
+    loss, grads, eps = grads_via_autograd(net, x_t, z, t, target)
+    rloss, rgrads, reps = ref_train.loss_and_grads(ref_unet.as_torch_sd(sd), x_t, z, t, target)
+    assert abs(float(loss) - float(rloss)) < 1e-5 * max(1.0, float(rloss))
+    check_grads(grads, rgrads, 3e-4, f"fp32 base={base} {ch_mult} {B}x{H}x{W}")
+
+
+def test_gradients_bf16_mode_close_to_fp32_oracle():
+    """bf16 activations / conv operands (what autocast does at train/diffusion_train.py:121): direction and size of every
+    gradient tensor agree with the fp32 oracle."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 64, (1, 2)))
+    B, S = 2, 64
+    g = torch.Generator("cpu").manual_seed(11)
+    x_t = torch.randn((B, 3, S, S), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.tensor([20, 700]); target = torch.randn((B, 3, S, S), generator=g)
+    net = make_net(sd, 64, (1, 2), dtype="bf16")
+    loss, grads, _ = grads_via_autograd(net, x_t, z, t, target)
+    rloss, rgrads, _ = ref_train.loss_and_grads(ref_unet.as_torch_sd(sd), x_t, z, t, target)
+    assert abs(float(loss) - float(rloss)) < 2e-2 * float(rloss)
+    worst = 1.0
+    for k, r in rgrads.items():
+        a = grads[k].double().flatten(); b = r.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.98, (k, cos)
+        assert 0.9 < float(a.norm() / (b.norm() + 1e-30)) < 1.1, k
+    print(f"bf16 gradients: worst cosine vs fp32 oracle {worst:.4f}")
+
+
+def test_fused_loss_and_adamw_match_oracle_over_three_steps():
+    """train_step (q_sample -> forward -> fused mse -> backward -> FusedAdamW) for three steps against the oracle loop."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    tables = ref_diffusion.scheduler_tables(1000, "cosine")
+    x0, z, t, noise = (torch.from_numpy(GOLD[k]) for k in ("x0", "z", "t", "noise"))
+    net = make_net(sd, 32, (1, 2))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    opt = FusedAdamW(net, lr=2e-4)
+    ref = ref_unet.as_torch_sd(sd)
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}; v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+    for step in range(1, 4):
+        loss = train_step(net, sch, opt, x0.to(DEV), z.to(DEV), t.to(DEV), noise.to(DEV))
+        rloss, rg, _, _ = ref_train.train_step_grads(ref, tables, x0, z, t, noise)
+        assert abs(float(loss) - float(rloss)) < 5e-5 * float(rloss), (step, float(loss), float(rloss))
+        for k in ref:
+            ref[k], m[k], v2[k] = ref_train.adamw_update(ref[k], rg[k], m[k], v2[k], step)
+    got = {k: p.detach().cpu() for k, p in net.named_parameters()}
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size, so compare the movement
+    init = ref_unet.as_torch_sd(sd)
+    for k in ref:
+        moved = (ref[k] - init[k]).abs().max()
+        assert float((got[k] - ref[k]).abs().max()) <= 0.05 * float(moved) + 1e-7, k
+    # the state dict still has the reference's keys and the parameters are views of one flat buffer
+    assert set(net.state_dict()) == set(sd)
+    assert net.train_state().fp.intact()
+
+
+def test_torch_optimizer_drop_in_and_eval_after_training():
+    """The reference's three lines with torch.optim.AdamW, then .eval() inference sees the updated weights."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4)
+    x0, z, t, noise = (torch.from_numpy(GOLD[k]).to(DEV) for k in ("x0", "z", "t", "noise"))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    losses = []
+    for _ in range(3):
+        x_t = sch.q_sample(x0, t, noise)
+        loss = F.mse_loss(net(x_t, z, t), noise)
+        loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+    assert losses[2] < losses[0]
+    net.eval()
+    with torch.no_grad():
+        e = net(x0, z, t)
+    ref = ref_unet.unet_forward(ref_unet.as_torch_sd({k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}), x0.cpu(), z.cpu(), t.cpu())
+    assert float((e.cpu() - ref).abs().max()) < 1e-4
+
+
+def test_backward_requires_matching_forward():
+    tr = _native.NativeTrainer(512, 32, (1, 2), 256, 3, device=DEV)
+    flat = torch.zeros(tr.total, device=DEV); x = torch.zeros((1, 3, 32, 32), device=DEV); z = torch.zeros((1, 512), device=DEV)
+    with pytest.raises(RuntimeError):
+        tr.backward(flat, torch.zeros_like(flat), x, z, torch.zeros_like(x))
+    with pytest.raises(ValueError):
+        tr.forward(flat, torch.zeros((1, 3, 30, 32), device=DEV), z, torch.zeros(1, dtype=torch.int64, device=DEV))
