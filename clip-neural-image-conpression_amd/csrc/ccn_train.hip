@@ -420,7 +420,7 @@ struct Walk {
         a.B = B; a.Hin = xin.H; a.Win = xin.W; a.Cin = w.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = w.Cout;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps; a.taps_w = w.kind == KIND_CT4 ? 16 : 9;
         a.n_ty = ceil_div(g.MH, 4); a.n_tx = ceil_div(g.MW, 32);
-        a.nsplit = wgrad_nsplit(w.kind, B, g.MH, g.MW, w.Cin, w.Cout);
+        a.nsplit = wgrad_nsplit(tr->cfg.dtype, w.kind, B, g.MH, g.MW, w.Cin, w.Cout);
         fill_taps(a.tapinfo, w.kind, false);
         want(need.scr_wg, (size_t)a.nsplit * a.taps_w * w.Cout * w.Cin * 4);
         const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, Hdy * Wdy, w.Cout);

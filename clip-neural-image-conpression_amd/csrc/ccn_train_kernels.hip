@@ -336,13 +336,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
         for (int e = 0; e < 8; ++e) o[e] = s1[e];
     }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ scratch, int rows, int C, float* __restrict__ db)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ scratch, int rows, int C, float* __restrict__ db)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < rows; ++k) s += (double)scratch[(size_t)k * C + c];
-    db[c] += (float)s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int k = rl; k < rows; k += 16) s += scratch[(size_t)k * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += (double)red[q][cl];
+        db[c] += (float)t;
+    }
 }
 hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s)
 {
@@ -351,28 +359,28 @@ hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, i
     const dim3 grid(g.nblk, B, g.zblocks);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
     else hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, B * g.nblk, C, db);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, scratch, B * g.nblk, C, db);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void nchw_chansum_kernel(const float* __restrict__ x, float* __restrict__ db, int B, int C, int64_t hw)
+__global__ __launch_bounds__(256) void nchw_chansum_kernel(const float* __restrict__ x, float* __restrict__ db, int C, int64_t hw, int chunks)
 {
     __shared__ double red[4];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x, b = blockIdx.y / chunks, ck = blockIdx.y % chunks, tid = threadIdx.x;
+    const int64_t per = (hw + chunks - 1) / chunks, i0 = ck * per, i1 = i0 + per < hw ? i0 + per : hw;
+    const float* p = x + ((size_t)b * C + c) * hw;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float* p = x + ((size_t)b * C + c) * hw;
-        for (int64_t i = tid; i < hw; i += 256) s += (double)p[i];
-    }
+    for (int64_t i = i0 + tid; i < i1; i += 256) s += (double)p[i];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) db[c] += (float)((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) atomicAdd(db + c, (float)((red[0] + red[1]) + (red[2] + red[3])));
 }
 hipError_t launch_nchw_chansum(const float* x, float* db, int B, int C, int64_t hw, hipStream_t s)
 {
-    hipLaunchKernelGGL(nchw_chansum_kernel, dim3(C), dim3(256), 0, s, x, db, B, C, hw);
+    const int chunks = (int)((hw + 8191) / 8192);
+    hipLaunchKernelGGL(nchw_chansum_kernel, dim3(C, B * chunks), dim3(256), 0, s, x, db, C, hw, chunks);
     return hipGetLastError();
 }
 
@@ -476,17 +484,125 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a)
     }
 }
 
+// bf16 mode: the same decomposition on v_mfma_f32_32x32x16_bf16.  The contraction index is the PIXEL, while the tiles in LDS are
+// channel-contiguous, so both operands are fetched with the transposing LDS read of gfx950 (ds_read_b64_tr_b16: a 16-lane group
+// reads 4 pixels x 16 channels and each lane receives 4 consecutive pixels of one channel).  LDS images are planes of
+// [pixel][32 channels] (64-byte rows): the four pixel rows of a transposed read then cover 64 distinct banks (conflict-free)
+// without padding; a wave works on one (Cout plane, Cin plane) pair of the workgroup's 64 x 64 tile.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+template <int IS, int NTAPS>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a)
+{
+    typedef __bf16 T;
+    constexpr int ROWS = WgGeom<IS>::ROWS, PITCH = WgGeom<IS>::PITCH, NPA = ROWS * PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;                                   // [2 planes][NPA pixels][32 ch] bf16
+    unsigned char* const Ds = smem + 2 * NPA * 64;                     // [2 planes][128 pixels][32 ch] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n_kt = (a.Cin + 63) / 64, n_nt = (a.Cout + 63) / 64;
+    int bid = blockIdx.x;
+    const int kt = bid % n_kt; bid /= n_kt;
+    const int nt = bid % n_nt; bid /= n_nt;
+    const int par = bid % a.npar; const int split = bid / a.npar;
+    const int k0 = kt * 64, n0 = nt * 64, py = par >> 1, px = par & 1, par_off = par * 4;
+
+    int toff[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) toff[t] = ((a.tapinfo_dy(par_off + t) + 1) * PITCH + a.tapinfo_dx(par_off + t) + 1) * 64;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    // transposed-read geometry of this lane: group g of 16 lanes -> pixels 8*(g>>1) + (0..3), channels 16*(g&1) + (0..15)
+    const int g = lane >> 4, pix_l = 8 * (g >> 1) + ((lane & 15) >> 2), c_l = 16 * (g & 1) + 4 * (lane & 3);
+    const unsigned char* const Dp = Ds + ((wn * 128 + pix_l) * 32 + c_l) * 2;
+    const unsigned char* const Ap = As + ((wk * NPA + IS * pix_l) * 32 + c_l) * 2;
+
+    const int tiles = a.B * a.n_ty * a.n_tx;
+    for (int tile = split; tile < tiles; tile += a.nsplit) {
+        const int tx = tile % a.n_tx, ty = (tile / a.n_tx) % a.n_ty, b = tile / (a.n_tx * a.n_ty);
+        const int my0 = ty * 4, mx0 = tx * 32;
+        __syncthreads();
+        {   // activated input halo: 8 chunks of 8 channels per pixel
+            const int ck = tid & 7, cbase = k0 + ck * 8;
+            const bool cvalid = cbase < a.Cin;
+            GnCoef<T> gk;
+            gk.load(a.gn_ab + (size_t)b * a.Cin + (cvalid ? cbase : 0), a.gn_ab != nullptr && cvalid);
+            const int iy0 = IS * my0 - 1, ix0 = IS * mx0 - 1;
+            unsigned char* const dst = As + ((ck >> 2) * NPA * 32 + (ck & 3) * 8) * 2;
+            for (int pxl = tid >> 3; pxl < NPA; pxl += 32) {
+                const int hy = pxl / PITCH, hx = pxl - hy * PITCH, iy = iy0 + hy, ix = ix0 + hx;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                    v = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
+                    if (a.gn_ab) v = gk.template apply<true>(v);
+                }
+                *(u32x4*)(dst + pxl * 64) = v;
+            }
+        }
+        {   // output gradient tile
+            const int ck = tid & 7, nbase = n0 + ck * 8;
+            unsigned char* const dst = Ds + ((ck >> 2) * 128 * 32 + (ck & 3) * 8) * 2;
+            for (int m = tid >> 3; m < 128; m += 32) {
+                const int my = my0 + (m >> 5), mx = mx0 + (m & 31);
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (nbase < a.Cout && my < a.MH && mx < a.MW)
+                    v = *(const u32x4*)((const T*)a.dy + ((size_t)(b * a.Hout + my * a.OS + py) * a.Wout + mx * a.OS + px) * a.Cout + nbase);
+                *(u32x4*)(dst + m * 64) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {                              // 16 pixels per step: row ks >> 1, columns 16 (ks & 1) ..
+            const s16x4 d0 = lds_tr16(Dp + ks * 1024), d1 = lds_tr16(Dp + ks * 1024 + 256);
+            const s16x8 dv = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            const unsigned char* const ap = Ap + (IS * (ks >> 1) * PITCH + IS * 16 * (ks & 1)) * 64;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const s16x4 a0 = lds_tr16(ap + toff[t]), a1 = lds_tr16(ap + toff[t] + 256 * IS);
+                const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dv), __builtin_bit_cast(bf16x8, av), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int k = k0 + wk * 32 + r;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int wt = a.tapinfo_w(par_off + t);
+        float* const o = a.part + ((size_t)split * a.taps_w + wt) * a.Cout * a.Cin;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n0 + wn * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (n < a.Cout && k < a.Cin) o[(size_t)n * a.Cin + k] = acc[t][q];
+        }
+    }
+}
+template <int IS> static constexpr size_t wgrad_bf16_lds() { return (size_t)(2 * WgGeom<IS>::ROWS * WgGeom<IS>::PITCH + 2 * 128) * 64; }
+
 template <int IS, int WN, int WK> static constexpr size_t wgrad_lds() { return (size_t)(WgGeom<IS>::ROWS * WgGeom<IS>::PITCH * 32 * WK + 128 * 32 * WN) * 4; }
 typedef void (*wgrad_fn_t)(const WgArgs);
 static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt)
 {
+    if (dtype == 1) {
+        *nt = 64; *kt = 64;
+        switch (kind) {
+            case KIND_C3S2: *lds = wgrad_bf16_lds<2>(); return (wgrad_fn_t)wgrad_bf16_kernel<2, 9>;
+            case KIND_CT4: *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 4>;
+            default: *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 9>;
+        }
+    }
     switch (kind) {
-        case KIND_C3S2: *lds = wgrad_lds<2, 4, 1>(); *nt = 128; *kt = 32;
-            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 2, 9, 4, 1> : (wgrad_fn_t)wgrad_kernel<__bf16, 2, 9, 4, 1>;
-        case KIND_CT4: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64;
-            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 1, 4, 2, 2> : (wgrad_fn_t)wgrad_kernel<__bf16, 1, 4, 2, 2>;
-        default: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64;
-            return dtype == 0 ? (wgrad_fn_t)wgrad_kernel<float, 1, 9, 2, 2> : (wgrad_fn_t)wgrad_kernel<__bf16, 1, 9, 2, 2>;
+        case KIND_C3S2: *lds = wgrad_lds<2, 4, 1>(); *nt = 128; *kt = 32; return (wgrad_fn_t)wgrad_kernel<float, 2, 9, 4, 1>;
+        case KIND_CT4: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 4, 2, 2>;
+        default: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 9, 2, 2>;
     }
 }
 hipError_t wgrad_prepare()
@@ -501,14 +617,14 @@ hipError_t wgrad_prepare()
         }
     return hipSuccess;
 }
-int wgrad_nsplit(int kind, int B, int MH, int MW, int Cin, int Cout)
+int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
 {
     size_t lds; int nt, kt;
-    (void)wgrad_pick(0, kind, &lds, &nt, &kt);
+    (void)wgrad_pick(dtype, kind, &lds, &nt, &kt);
     const int npar = kind == KIND_CT4 ? 4 : 1;
     const int tiles = B * ((MH + 3) / 4) * ((MW + 31) / 32);
     const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
-    int ns = (768 + groups - 1) / groups;                         // ~3 workgroups per CU
+    int ns = ((dtype == 1 ? 512 : 768) + groups - 1) / groups;     // 2-3 workgroups per CU
     if (ns > tiles) ns = tiles;
     return ns < 1 ? 1 : ns;
 }
@@ -543,7 +659,7 @@ hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, i
 }
 
 // stem / head: block = (8 image rows, sample, channel block); thread -> (channel, pixel lane), 27 accumulators (img_ch <= 3)
-constexpr int WS_ROWS = 8;
+constexpr int WS_ROWS = 2;
 int wsmall_blocks(int H) { return (H + WS_ROWS - 1) / WS_ROWS; }
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ xn, const float2* __restrict__ gn_ab, const float* __restrict__ img,
@@ -569,13 +685,23 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
         }
         __syncthreads();
         if (act)
-            for (int x = xl; x < W; x += lanes) {
-                float v = from_elem<T>(xn[((size_t)(b * H + y) * W + x) * C + c]);
-                if (gn_ab) v = fmaf(v, a, cc);
+            for (int x0 = xl; x0 < W; x0 += 4 * lanes) {
+                float v[4];
 #pragma unroll
-                for (int j = 0; j < 27; ++j) {
-                    const int ch = j / 9, t = j % 9, dy = t / 3 - 1, dx = t % 3 - 1;
-                    if (ch < img_ch) acc[j] = fmaf(v, simg[(ch * 3 + 1 + sgn * dy) * WP + x + 1 + sgn * dx], acc[j]);
+                for (int u = 0; u < 4; ++u) {                       // four loads in flight
+                    const int x = x0 + u * lanes;
+                    v[u] = x < W ? from_elem<T>(xn[((size_t)(b * H + y) * W + x) * C + c]) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * lanes;
+                    if (x >= W) break;
+                    const float vv = gn_ab ? fmaf(v[u], a, cc) : v[u];
+#pragma unroll
+                    for (int j = 0; j < 27; ++j) {
+                        const int ch = j / 9, t = j % 9, dy = t / 3 - 1, dx = t % 3 - 1;
+                        if (ch < img_ch) acc[j] = fmaf(vv, simg[(ch * 3 + 1 + sgn * dy) * WP + x + 1 + sgn * dx], acc[j]);
+                    }
                 }
             }
     }
@@ -667,19 +793,36 @@ hipError_t launch_tlinear_dw(const float* dy, int lddy, const float* x, int ldx,
     hipLaunchKernelGGL(tlinear_dw_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, dy, lddy, x, ldx, dW, db, R, K, N);
     return hipGetLastError();
 }
-__global__ void tlinear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ W, float* __restrict__ dx, int lddx, int R,
-                                  int K, int N, int accumulate)
+// dx[r][k] = sum_n dy[r][n] W[n][k]: block = 64 k x 4 waves over n, 4 rows r per block share every weight load
+__global__ __launch_bounds__(256) void tlinear_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ W, float* __restrict__ dx,
+                                                          int lddx, int R, int K, int N, int accumulate)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (k >= K) return;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc = fmaf(dy[(size_t)r * lddy + n], W[(size_t)n * K + k], acc);
-    float* o = dx + (size_t)r * lddx + k;
-    *o = accumulate ? *o + acc : acc;
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, r0 = blockIdx.y * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int kk = k < K ? k : K - 1;
+#pragma unroll 4
+    for (int n = wave; n < N; n += 4) {
+        const float w = W[(size_t)n * K + kk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int r = r0 + j < R ? r0 + j : R - 1; acc[j] = fmaf(dy[(size_t)r * lddy + n], w, acc[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    if (wave == 0 && k < K)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + j < R) {
+                const float v = (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]);
+                float* o = dx + (size_t)(r0 + j) * lddx + k;
+                *o = accumulate ? *o + v : v;
+            }
 }
 hipError_t launch_tlinear_dx(const float* dy, int lddy, const float* W, float* dx, int lddx, int R, int K, int N, int accumulate, hipStream_t s)
 {
-    hipLaunchKernelGGL(tlinear_dx_kernel, dim3((K + 255) / 256, R), dim3(256), 0, s, dy, lddy, W, dx, lddx, R, K, N, accumulate);
+    hipLaunchKernelGGL(tlinear_dx_kernel, dim3((K + 63) / 64, (R + 3) / 4), dim3(256), 0, s, dy, lddy, W, dx, lddx, R, K, N, accumulate);
     return hipGetLastError();
 }
 __global__ void silu_bwd_kernel(float* __restrict__ du, const float* __restrict__ dy, const float* __restrict__ u, int64_t n)
