@@ -59,6 +59,11 @@ struct TT {                                     // an NHWC activation and the pa
     float2* part = nullptr; int n_sp = 0, n_nt = 0, bn = 0;
 };
 
+enum { TF_PACK = 0, TF_COND, TF_CONV_FWD, TF_GN_STATS, TF_CONV_DGRAD, TF_WGRAD, TF_WGRAD_REDUCE, TF_BIAS, TF_GN_BWD, TF_SMALL, TF_COUNT };
+const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd", "conv_forward", "gn_stats", "conv_data_grad", "conv_weight_grad",
+                                        "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
+struct Mark { int fam; hipEvent_t ev; double flops; };
+
 struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, scr_small = 0, tensors = 0, total = 0; };
 
 }  // namespace
@@ -78,6 +83,10 @@ struct ccn_trainer_s {
     float* zero_bias = nullptr;
     std::vector<void*> allocs;
     std::map<std::string, ShapeInfo> shapes;
+    // profiling (ccn_train_profile_*): an event before every group of launches; the time up to the next event is the group's
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<Mark> marks;
     // state of the last forward (checked by backward)
     int fB = 0, fH = 0, fW = 0; void* fws = nullptr; const float* fx = nullptr;
 };
@@ -237,6 +246,15 @@ struct Walk {
     Walk(ccn_trainer_s* t, int B_, int H_, int W_, void* ws, bool l, hipStream_t s, const float* p, float* g)
         : tr(t), B(B_), H(H_), W(W_), base((char*)ws), launch(l), st(s), P(p), Gd(g) {}
 
+    // profiling: the launches that follow belong to family `fam` (flops: their algorithmic work); fam < 0 closes the sequence
+    void mark(int fam, double flops = 0.0)
+    {
+        if (!launch || !tr->profiling) return;
+        if (tr->ev_used == tr->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; tr->ev_pool.push_back(e); }
+        hipEvent_t e = tr->ev_pool[tr->ev_used++];
+        if (hipEventRecord(e, st) != hipSuccess) return;
+        tr->marks.push_back({fam, e, flops});
+    }
     void* take(size_t bytes) { off = align_up(off, 256); void* p = base ? base + off : nullptr; off += bytes; return p; }
     TT new_tensor(int C, int h, int w) { TT t; t.C = C; t.H = h; t.W = w; t.p = take((size_t)B * h * w * C * tr->elem); return t; }
     int groups_for(int C) const { return C < tr->G ? C : tr->G; }
@@ -254,6 +272,7 @@ struct Walk {
     bool pack(const TConvW& w)
     {
         if (!launch) return true;
+        mark(TF_PACK);
         const int dt = tr->cfg.dtype;
         const float* src = par(w.pw);
         switch (w.kind) {
@@ -273,7 +292,7 @@ struct Walk {
     }
 
     // generic launch of the forward conv kernels.  `kind`: kernel family; N = output channels of this launch, K = input channels
-    bool run_conv(int kind, bool four, const void* wop, int BN, int K, int Kpad, int N, int Npad, const float* bias, const void* in, int Hin, int Win,
+    bool run_conv(int fam, int kind, bool four, const void* wop, int BN, int K, int Kpad, int N, int Npad, const float* bias, const void* in, int Hin, int Win,
                   TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out)
     {
         const Geom g = geom_of(kind, Hin, Win, four);
@@ -302,18 +321,19 @@ struct Walk {
             a.part = out->part;
         }
         if (!launch) return true;
+        mark(fam, 2.0 * B * g.Hout * g.Wout * (double)N * (kind == KIND_CT4 ? 4 : (kind == KIND_STEM ? 1 : g.ntaps)) * (kind == KIND_STEM ? 9.0 * K : (double)K));
         return ok(launch_conv(tr->cfg.dtype, kind, BN, a, st), "conv");
     }
     bool conv_fwd(const TConvW& w, const TT& in, TT& out, const float2* gn_ab, const float* film, const TT* res, bool want_part, const void* in_override = nullptr,
                   float* eps_out = nullptr)
     {
-        return run_conv(w.kind, false, w.wf, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
+        return run_conv(TF_CONV_FWD, w.kind, false, w.wf, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
                         &out, out.p, gn_ab, film, res ? res->p : nullptr, want_part, eps_out);
     }
     // dX = conv'(dY): N = the forward conv's Cin
     bool conv_dgrad(const TConvW& w, const void* dy, int Hdy, int Wdy, void* dx, const void* res)
     {
-        return run_conv(w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
+        return run_conv(TF_CONV_DGRAD, w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
                         nullptr, dx, nullptr, nullptr, res, false, nullptr);
     }
     bool gn_fwd(const TT& t, const TNorm& n, float2*& ab, float2*& stats)
@@ -322,6 +342,7 @@ struct Walk {
         ab = (float2*)take((size_t)B * t.C * sizeof(float2));
         stats = (float2*)take((size_t)B * G * sizeof(float2));
         if (!launch) return true;
+        mark(TF_GN_STATS);
         return ok(launch_gn_stats(t.part, B, G, t.n_sp, t.n_nt, t.bn, cpg, t.C, (double)cpg * t.H * t.W, par(n.pg), par(n.pb), 1e-5f, ab, stats, st), "gn_stats");
     }
 
@@ -333,6 +354,7 @@ struct Walk {
         tp = (float*)take((size_t)B * td * 4); uz = (float*)take((size_t)B * td * 4); zpv = (float*)take((size_t)B * td * 4);
         hv = (float*)take((size_t)B * td * 4); film = (float*)take((size_t)B * tr->F * 4);
         if (!launch) return true;
+        mark(TF_COND);
         if (!ok(launch_temb_i64(t, temb, B, td, st), "temb")) return false;
         if (!ok(launch_tlinear_fwd(temb, td, par(tr->tp0.pw), par(tr->tp0.pb), t1, 4 * td, u0, B, td, 4 * td, 1, st), "time_proj.0")) return false;
         if (!ok(launch_tlinear_fwd(t1, 4 * td, par(tr->tp2.pw), par(tr->tp2.pb), tp, td, nullptr, B, 4 * td, td, 0, st), "time_proj.2")) return false;
@@ -399,7 +421,7 @@ struct Walk {
                     head_in = x;
                     if (!gn_fwd(x, tr->out_norm, ab_o, st_o)) return false;
                     TT none;
-                    if (!run_conv(KIND_HEAD, false, tr->head.wf, tr->head.BN, tr->head.Cin, tr->head.Cin_pad, tr->head.Cout, tr->head.Cout_pad,
+                    if (!run_conv(TF_CONV_FWD, KIND_HEAD, false, tr->head.wf, tr->head.BN, tr->head.Cin, tr->head.Cin_pad, tr->head.Cout, tr->head.Cout_pad,
                                   launch ? par(tr->head.pb) : nullptr, x.p, x.H, x.W, &none, nullptr, ab_o, nullptr, nullptr, false, eps)) return false;
                     break;
                 }
@@ -427,8 +449,11 @@ struct Walk {
         want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
         (void)Hdy; (void)Wdy;
         if (!launch) return true;
+        mark(TF_WGRAD, 2.0 * B * g.Hout * g.Wout * (double)w.Cout * (w.kind == KIND_CT4 ? 4 : 9) * w.Cin);
         if (!ok(launch_wgrad(tr->cfg.dtype, w.kind, a, st), "wgrad")) return false;
+        mark(TF_WGRAD_REDUCE);
         if (!ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, w.Cout, w.Cin, w.kind == KIND_CT4 ? 1 : 0, grad(w.pw), st), "wgrad_reduce")) return false;
+        mark(TF_BIAS);
         return ok(launch_colsum(tr->cfg.dtype, dy, scr_col, grad(w.pb), B, g.Hout * g.Wout, w.Cout, st), "bias_grad");
     }
     // GroupNorm(+SiLU) backward of the norm reading tensor `x`: dA -> out (may alias dA)
@@ -444,6 +469,7 @@ struct Walk {
         float2* gstat = (float2*)take((size_t)B * G * sizeof(float2));
         if (!launch) return true;
         const int dt = tr->cfg.dtype;
+        mark(TF_GN_BWD);
         if (!ok(launch_gn_bwd_reduce(dt, x.p, dA, ab, stats, scr_gn, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_reduce")) return false;
         if (!ok(launch_gn_bwd_finalize(scr_gn, gg.nblk, B, x.C, cpg, G, (double)cpg * HW, par(n.pg), gstat, grad(n.pg), grad(n.pb), st), "gn_bwd_finalize")) return false;
         if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, film_r ? scr_film : nullptr, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))
@@ -477,6 +503,7 @@ struct Walk {
                     // out.weight / out.bias
                     want(need.scr_small, (size_t)B * wsmall_blocks(H) * u.C * 27 * 4);
                     if (launch) {
+                        mark(TF_SMALL);
                         if (!ok(launch_wgrad_small(dt, u.p, ab_o, d_eps, c.img_ch, -1, scr_small, B, H, W, u.C, st), "head_wgrad")) return false;
                         if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), u.C, c.img_ch, 1, grad(w.pw), st), "head_wgrad_reduce")) return false;
                         if (!ok(launch_nchw_chansum(d_eps, grad(w.pb), B, c.img_ch, (int64_t)H * W, st), "head_bias")) return false;
@@ -527,6 +554,7 @@ struct Walk {
                     const GnBwdGeom gg = gn_bwd_geom(dt, H * W, w.Cout);
                     want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
                     if (launch) {
+                        mark(TF_SMALL);
                         if (!ok(launch_wgrad_small(dt, g.p, nullptr, x_t, c.img_ch, +1, scr_small, B, H, W, w.Cout, st), "stem_wgrad")) return false;
                         if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), w.Cout, c.img_ch, 0, grad(w.pw), st), "stem_wgrad_reduce")) return false;
                         if (!ok(launch_colsum(dt, g.p, scr_col, grad(w.pb), B, H * W, w.Cout, st), "stem_bias")) return false;
@@ -537,6 +565,7 @@ struct Walk {
         }
         // conditioning: film_r = h W_r^T + b_r for every block; h = time_proj(temb(t)) + z_proj(z)
         if (!launch) return true;
+        mark(TF_COND);
         bool first = true;
         for (const TRes& r : tr->res) {
             if (!lin_bwd(r.fs, dfilm + r.film_off, tr->F, hv, td, dh, td, first ? 0 : 1)) return false;
@@ -612,6 +641,7 @@ int ccn_train_destroy(ccn_trainer_t tr)
 {
     if (!tr) return CCN_OK;
     for (void* p : tr->allocs) (void)hipFree(p);
+    for (hipEvent_t e : tr->ev_pool) (void)hipEventDestroy(e);
     delete tr;
     return CCN_OK;
 }
@@ -657,6 +687,7 @@ int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_
     Walk w(tr, B, H, W, workspace_dev, true, (hipStream_t)stream, params_dev, nullptr);
     w.place_scratch(si);
     if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) return tfail(CCN_EHIP, w.err);
+    w.mark(-1);
     tr->fB = B; tr->fH = H; tr->fW = W; tr->fws = workspace_dev; tr->fx = x_t_dev;
     return CCN_OK;
 }
@@ -676,6 +707,33 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
     if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) return tfail(CCN_EHIP, w.err);
     w.launch = true;
     if (!w.backward(x_t_dev, z_dev, d_eps_dev)) return tfail(CCN_EHIP, w.err);
+    w.mark(-1);
+    return CCN_OK;
+}
+
+int ccn_train_profile_enable(ccn_trainer_t tr, int32_t on)
+{
+    if (!tr) return tfail(CCN_EINVAL, "null handle");
+    tr->profiling = on != 0;
+    tr->marks.clear(); tr->ev_used = 0;
+    return CCN_OK;
+}
+
+int ccn_train_profile_read(ccn_trainer_t tr, const char** names, float* ms, int32_t* calls, double* flops, int32_t cap, int32_t* n)
+{
+    if (!tr || !names || !ms || !calls || !flops || !n) return tfail(CCN_EINVAL, "null argument");
+    if (cap < TF_COUNT) return tfail(CCN_EINVAL, "cap too small");
+    if (hipDeviceSynchronize() != hipSuccess) return tfail(CCN_EHIP, "hipDeviceSynchronize failed");
+    for (int f = 0; f < TF_COUNT; ++f) { names[f] = kTrainFamilies[f]; ms[f] = 0.f; calls[f] = 0; flops[f] = 0.0; }
+    for (size_t i = 0; i + 1 < tr->marks.size(); ++i) {
+        const Mark& m = tr->marks[i];
+        if (m.fam < 0) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, m.ev, tr->marks[i + 1].ev) != hipSuccess) return tfail(CCN_EHIP, "hipEventElapsedTime failed");
+        ms[m.fam] += t; calls[m.fam] += 1; flops[m.fam] += m.flops;
+    }
+    *n = TF_COUNT;
+    tr->marks.clear(); tr->ev_used = 0;
     return CCN_OK;
 }
 

@@ -52,3 +52,35 @@ def test_two_rank_eval_matches_single_process(tmp_path):
     one, two = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert one.shape == (N, 4) and np.isfinite(one[:, 0]).all()
     assert np.array_equal(one, two, equal_nan=True)
+
+
+# ---- data-parallel training step: per-rank gradients of half batches, one all-reduce --------------
+def _train_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from oracle import ref_unet, ref_train
+    from clip_feature_codec.train.diffusion_train import average_gradients
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = synth.unet_param_spec(512, 8, (1,))
+    sd = ref_unet.as_torch_sd(synth.synth_state_dict(spec))
+    g = torch.Generator("cpu").manual_seed(3)
+    B = 4
+    x = torch.randn((B, 3, 16, 16), generator=g); z = torch.from_numpy(synth.synth_z(B)); t = torch.tensor([5, 300, 650, 999])
+    target = torch.randn((B, 3, 16, 16), generator=g)
+    lo, hi = (rank * B // world, (rank + 1) * B // world)
+    _, grads, _ = ref_train.loss_and_grads(sd, x[lo:hi], z[lo:hi], t[lo:hi], target[lo:hi])
+    flat = torch.cat([grads[k].flatten() for k, _ in spec])           # the flat gradient buffer of this rank
+    average_gradients(flat)
+    if rank == 0:
+        np.save(out, flat.numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch_gradient(tmp_path):
+    _train_rank(0, 1, 0, str(tmp_path / "g1.npy"))
+    mp.spawn(_train_rank, args=(2, 29547, str(tmp_path / "g2.npy")), nprocs=2, join=True)
+    g1, g2 = np.load(tmp_path / "g1.npy"), np.load(tmp_path / "g2.npy")
+    assert g1.shape == g2.shape and np.abs(g1).max() > 0
+    assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max()
