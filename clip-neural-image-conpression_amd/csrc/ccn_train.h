@@ -36,8 +36,11 @@ hipError_t launch_gn_bwd_finalize(const float2* part, int nblk, int B, int C, in
 hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, const float2* gstat,
                                const void* addend, void* out, const float* film, int film_bstride, float2* fpart,
                                int B, int HW, int C, int cpg, int G, int silu, hipStream_t s);
-hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, int B, int C,
-                                    hipStream_t s);
+hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, float* dbias, int B,
+                                    int C, hipStream_t s);
+// without FiLM the apply pass leaves per-(sample, block, channel) sums of its OUTPUT in fpart: the bias gradient of the conv
+// whose output gradient that is
+hipError_t launch_colsum_from_pairs(const float2* part, int rows, int C, float* db, hipStream_t s);
 // per-channel sum over (B, HW) of an NHWC tensor, added to `db` (bias gradients); scratch: B * nblk * C floats
 hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s);
 // per-channel sum of an NCHW fp32 tensor, added to db

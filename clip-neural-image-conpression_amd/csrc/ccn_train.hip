@@ -242,6 +242,7 @@ struct Walk {
     std::vector<ResSave> rs;
     TT stem_out; std::vector<TT> down_in, down_out, up_in, up_out;
     TT head_in; float2 *ab_o = nullptr, *st_o = nullptr;
+    int g_sum_rows = 0;                   // > 0: scr_film holds per-block channel sums of the current gradient tensor (rows = B * blocks)
 
     Walk(ccn_trainer_s* t, int B_, int H_, int W_, void* ws, bool l, hipStream_t s, const float* p, float* g)
         : tr(t), B(B_), H(H_), W(W_), base((char*)ws), launch(l), st(s), P(p), Gd(g) {}
@@ -333,6 +334,7 @@ struct Walk {
     // dX = conv'(dY): N = the forward conv's Cin
     bool conv_dgrad(const TConvW& w, const void* dy, int Hdy, int Wdy, void* dx, const void* res)
     {
+        g_sum_rows = 0;                                         // the gradient tensor that follows comes out of a conv: no channel sums
         return run_conv(TF_CONV_DGRAD, w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
                         nullptr, dx, nullptr, nullptr, res, false, nullptr);
     }
@@ -434,7 +436,7 @@ struct Walk {
     void want(size_t& slot, size_t bytes) { if (bytes > slot) slot = bytes; }
 
     // dW (and db) of a conv: A = act(GN(x)) redone on the fly, dY given
-    bool conv_wgrad(const TConvW& w, const TT& xin, const float2* gn_ab, const void* dy, int Hdy, int Wdy)
+    bool conv_wgrad(const TConvW& w, const TT& xin, const float2* gn_ab, const void* dy, int Hdy, int Wdy, bool bias_done = false)
     {
         const Geom g = geom_of(w.kind, xin.H, xin.W, false);
         WgArgs a{};
@@ -453,28 +455,31 @@ struct Walk {
         if (!ok(launch_wgrad(tr->cfg.dtype, w.kind, a, st), "wgrad")) return false;
         mark(TF_WGRAD_REDUCE);
         if (!ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, w.Cout, w.Cin, w.kind == KIND_CT4 ? 1 : 0, grad(w.pw), st), "wgrad_reduce")) return false;
+        if (bias_done) return true;
         mark(TF_BIAS);
+        if (g_sum_rows > 0) return ok(launch_colsum_from_pairs(scr_film, g_sum_rows, w.Cout, grad(w.pb), st), "bias_grad");
         return ok(launch_colsum(tr->cfg.dtype, dy, scr_col, grad(w.pb), B, g.Hout * g.Wout, w.Cout, st), "bias_grad");
     }
     // GroupNorm(+SiLU) backward of the norm reading tensor `x`: dA -> out (may alias dA)
     bool gn_bwd(const TT& x, const TNorm& n, const float2* ab, const float2* stats, const void* dA, void* out, bool silu, const void* addend,
-                int film_off)
+                int film_off, float* film_bias = nullptr)
     {
         const int G = groups_for(x.C), cpg = x.C / G, HW = x.H * x.W;
         const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, HW, x.C);
         want(need.scr_gn, (size_t)B * gg.nblk * x.C * sizeof(float2));
-        if (film_off >= 0) want(need.scr_film, (size_t)B * gg.nblk * x.C * sizeof(float2));
+        want(need.scr_film, (size_t)B * gg.nblk * x.C * sizeof(float2));
         const float* film_r = film_off >= 0 && film ? film + film_off : nullptr;
         float* dfilm_r = film_off >= 0 && dfilm ? dfilm + film_off : nullptr;
+        g_sum_rows = film_off >= 0 ? 0 : B * gg.nblk;
         float2* gstat = (float2*)take((size_t)B * G * sizeof(float2));
         if (!launch) return true;
         const int dt = tr->cfg.dtype;
         mark(TF_GN_BWD);
         if (!ok(launch_gn_bwd_reduce(dt, x.p, dA, ab, stats, scr_gn, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_reduce")) return false;
         if (!ok(launch_gn_bwd_finalize(scr_gn, gg.nblk, B, x.C, cpg, G, (double)cpg * HW, par(n.pg), gstat, grad(n.pg), grad(n.pb), st), "gn_bwd_finalize")) return false;
-        if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, film_r ? scr_film : nullptr, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))
+        if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, scr_film, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))
             return false;
-        if (film_r) return ok(launch_film_bwd_finalize(scr_film, gg.nblk, film_r, tr->F, dfilm_r, B, x.C, st), "film_bwd");
+        if (film_r) return ok(launch_film_bwd_finalize(scr_film, gg.nblk, film_r, tr->F, dfilm_r, film_bias, B, x.C, st), "film_bwd");
         return true;
     }
     bool lin_bwd(const TLin& l, const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int accumulate)
@@ -540,8 +545,8 @@ struct Walk {
                     if (!conv_wgrad(r.c2, s.y, s.ab2, g.p, g.H, g.W)) return false;
                     TT g1 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c2, g.p, g.H, g.W, g1.p, nullptr)) return false;
-                    if (!gn_bwd(s.y, r.n2, s.ab2, s.st2, g1.p, g1.p, true, nullptr, r.film_off)) return false;
-                    if (!conv_wgrad(r.c1, s.x, s.ab1, g1.p, g.H, g.W)) return false;
+                    if (!gn_bwd(s.y, r.n2, s.ab2, s.st2, g1.p, g1.p, true, nullptr, r.film_off, launch ? grad(r.c1.pb) : nullptr)) return false;
+                    if (!conv_wgrad(r.c1, s.x, s.ab1, g1.p, g.H, g.W, true)) return false;
                     TT g2 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c1, g1.p, g.H, g.W, g2.p, nullptr)) return false;
                     if (!gn_bwd(s.x, r.n1, s.ab1, s.st1, g2.p, g2.p, true, g.p, -1)) return false;
@@ -557,7 +562,8 @@ struct Walk {
                         mark(TF_SMALL);
                         if (!ok(launch_wgrad_small(dt, g.p, nullptr, x_t, c.img_ch, +1, scr_small, B, H, W, w.Cout, st), "stem_wgrad")) return false;
                         if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), w.Cout, c.img_ch, 0, grad(w.pw), st), "stem_wgrad_reduce")) return false;
-                        if (!ok(launch_colsum(dt, g.p, scr_col, grad(w.pb), B, H * W, w.Cout, st), "stem_bias")) return false;
+                        if (g_sum_rows > 0) { if (!ok(launch_colsum_from_pairs(scr_film, g_sum_rows, w.Cout, grad(w.pb), st), "stem_bias")) return false; }
+                        else if (!ok(launch_colsum(dt, g.p, scr_col, grad(w.pb), B, H * W, w.Cout, st), "stem_bias")) return false;
                     }
                     break;
                 }

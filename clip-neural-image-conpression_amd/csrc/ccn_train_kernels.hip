@@ -15,6 +15,7 @@
 //   adamw_kernel, mse_loss_grad
 #include "ccn_device.h"
 #include "ccn_train.h"
+#include <cstdlib>
 
 namespace ccn {
 
@@ -263,10 +264,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                 if (silu) da *= dsilu<T>(fmaf(xv[e], a[e], c[e]));
                 const float xh = (xv[e] - mu[e]) * rs[e];
                 const float dx = a[e] * da - rs[e] * fmaf(xh, m2[e], m1[e]);
-                s1[e] += dx; s2[e] = fmaf(dx, xv[e], s2[e]);
                 float o = dx * fs[e];
                 if (addend) o += rv[e];
                 ov[e] = o;
+                s1[e] += film ? dx : o; s2[e] = fmaf(dx, xv[e], s2[e]);
             }
             Chunk<T>::store(out + off, ov);
         }
@@ -293,7 +294,7 @@ hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const f
 // d scale[b][c] = sum dF * y1, y1 = (F - shift) / (1 + scale); d shift[b][c] = sum dF   (F = y1 (1 + scale) + shift is what the
 // forward stored; a block whose 1 + scale is exactly zero has lost y1 and gets d scale = 0)
 __global__ void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int nblk, const float* __restrict__ film, int film_bstride,
-                                         float* __restrict__ dfilm, int C)
+                                         float* __restrict__ dfilm, int C, float* __restrict__ dbias)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (c >= C) return;
@@ -302,10 +303,13 @@ __global__ void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int n
     const float sc = 1.0f + film[(size_t)b * film_bstride + c], sft = film[(size_t)b * film_bstride + C + c];
     dfilm[(size_t)b * film_bstride + c] = sc != 0.f ? (float)((s2 - (double)sft * s1) / (double)sc) : 0.f;
     dfilm[(size_t)b * film_bstride + C + c] = (float)s1;
+    // the conv in front of the FiLM: d bias[c] = sum over pixels of dF (1 + scale)
+    if (dbias) atomicAdd(dbias + c, (float)((double)sc * s1));
 }
-hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, int B, int C, hipStream_t s)
+hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, float* dbias, int B, int C,
+                                    hipStream_t s)
 {
-    hipLaunchKernelGGL(film_bwd_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, fpart, nblk, film, film_bstride, dfilm, C);
+    hipLaunchKernelGGL(film_bwd_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, fpart, nblk, film, film_bstride, dfilm, C, dbias);
     return hipGetLastError();
 }
 
@@ -351,6 +355,28 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
         for (int q = 0; q < 16; ++q) t += (double)red[q][cl];
         db[c] += (float)t;
     }
+}
+// the same from the (sum, -) pairs the GroupNorm-backward apply pass leaves behind
+__global__ __launch_bounds__(256) void colsum_pair_finalize_kernel(const float2* __restrict__ part, int rows, int C, float* __restrict__ db)
+{
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int k = rl; k < rows; k += 16) s += part[(size_t)k * C + c].x;
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += (double)red[q][cl];
+        db[c] += (float)t;
+    }
+}
+hipError_t launch_colsum_from_pairs(const float2* part, int rows, int C, float* db, hipStream_t s)
+{
+    hipLaunchKernelGGL(colsum_pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, rows, C, db);
+    return hipGetLastError();
 }
 hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s)
 {
@@ -531,33 +557,50 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a)
         const int tx = tile % a.n_tx, ty = (tile / a.n_tx) % a.n_ty, b = tile / (a.n_tx * a.n_ty);
         const int my0 = ty * 4, mx0 = tx * 32;
         __syncthreads();
-        {   // activated input halo: 8 chunks of 8 channels per pixel
-            const int ck = tid & 7, cbase = k0 + ck * 8;
+        {   // activated input halo (8 chunks of 8 channels per pixel) and the output-gradient tile: every global load is issued
+            // before the first use, then transformed and written to LDS
+            constexpr int NA = (NPA + 31) / 32;
+            const int ck = tid & 7, cbase = k0 + ck * 8, nbase = n0 + ck * 8;
             const bool cvalid = cbase < a.Cin;
             GnCoef<T> gk;
             gk.load(a.gn_ab + (size_t)b * a.Cin + (cvalid ? cbase : 0), a.gn_ab != nullptr && cvalid);
             const int iy0 = IS * my0 - 1, ix0 = IS * mx0 - 1;
-            unsigned char* const dst = As + ((ck >> 2) * NPA * 32 + (ck & 3) * 8) * 2;
-            for (int pxl = tid >> 3; pxl < NPA; pxl += 32) {
-                const int hy = pxl / PITCH, hx = pxl - hy * PITCH, iy = iy0 + hy, ix = ix0 + hx;
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-                    v = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
-                    if (a.gn_ab) v = gk.template apply<true>(v);
-                }
-                *(u32x4*)(dst + pxl * 64) = v;
-            }
-        }
-        {   // output gradient tile
-            const int ck = tid & 7, nbase = n0 + ck * 8;
-            unsigned char* const dst = Ds + ((ck >> 2) * 128 * 32 + (ck & 3) * 8) * 2;
-            for (int m = tid >> 3; m < 128; m += 32) {
-                const int my = my0 + (m >> 5), mx = mx0 + (m & 31);
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            u32x4 rd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (tid >> 3) + 32 * i, my = my0 + (m >> 5), mx = mx0 + (m & 31);
+                rd[i] = u32x4{0u, 0u, 0u, 0u};
                 if (nbase < a.Cout && my < a.MH && mx < a.MW)
-                    v = *(const u32x4*)((const T*)a.dy + ((size_t)(b * a.Hout + my * a.OS + py) * a.Wout + mx * a.OS + px) * a.Cout + nbase);
-                *(u32x4*)(dst + m * 64) = v;
+                    rd[i] = *(const u32x4*)((const T*)a.dy + ((size_t)(b * a.Hout + my * a.OS + py) * a.Wout + mx * a.OS + px) * a.Cout + nbase);
             }
+            unsigned char* const dstA = As + ((ck >> 2) * NPA * 32 + (ck & 3) * 8) * 2;
+            constexpr int GRP = NA < 8 ? NA : 8;
+#pragma unroll
+            for (int g0 = 0; g0 < NA; g0 += GRP) {
+                u32x4 ra[GRP]; unsigned okm = 0;
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int pxl = (tid >> 3) + 32 * (g0 + u);
+                    const int hy = pxl / PITCH, hx = pxl - hy * PITCH, iy = iy0 + hy, ix = ix0 + hx;
+                    ra[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (g0 + u < NA && pxl < NPA && cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                        okm |= 1u << u;
+                        ra[u] = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int pxl = (tid >> 3) + 32 * (g0 + u);
+                    if (g0 + u < NA && pxl < NPA) {
+                        u32x4 v = ra[u];
+                        if (((okm >> u) & 1u) && a.gn_ab) v = gk.template apply<true>(v);
+                        *(u32x4*)(dstA + pxl * 64) = v;
+                    }
+                }
+            }
+            unsigned char* const dstD = Ds + ((ck >> 2) * 128 * 32 + (ck & 3) * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(dstD + ((tid >> 3) + 32 * i) * 64) = rd[i];
         }
         __syncthreads();
 #pragma unroll 2
@@ -624,7 +667,8 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
     const int npar = kind == KIND_CT4 ? 4 : 1;
     const int tiles = B * ((MH + 3) / 4) * ((MW + 31) / 32);
     const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
-    int ns = ((dtype == 1 ? 512 : 768) + groups - 1) / groups;     // 2-3 workgroups per CU
+    static const int target_bf16 = getenv("CCN_WGRAD_WGS") ? atoi(getenv("CCN_WGRAD_WGS")) : 512;
+    int ns = ((dtype == 1 ? target_bf16 : 768) + groups - 1) / groups;     // 2-3 workgroups per CU
     if (ns > tiles) ns = tiles;
     return ns < 1 ? 1 : ns;
 }
