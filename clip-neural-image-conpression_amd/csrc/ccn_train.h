@@ -19,6 +19,17 @@ enum PackMode {
 };
 hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s);
 
+// all repacks of one step in ONE launch: descriptor table built once at create time (offsets into the flat parameter buffer)
+struct PackDesc { long long src_off; void* dst; int mode, O, I, taps, Np, Kp; };
+hipError_t launch_pack_group(int dtype, const float* params, const PackDesc* descs_dev, int n, hipStream_t s);
+
+// the FiLM linears of every ResBlock (to_scale / to_shift: models/blocks.py:19-20) share their input h: one launch each for the
+// forward, the weight/bias gradients and the input gradient.  out_off: column of the (B, F) FiLM table.
+struct LinDesc { long long w_off, b_off; int N, out_off; };
+hipError_t launch_film_group_fwd(const float* params, const LinDesc* d, int n, int maxN, const float* h, float* film, int B, int K, int F, hipStream_t s);
+hipError_t launch_film_group_dw(float* grads, const LinDesc* d, int n, int maxN, const float* dfilm, const float* h, int B, int K, int F, hipStream_t s);
+hipError_t launch_film_group_dx(const float* params, const LinDesc* d, int n, const float* dfilm, float* dh, int B, int K, int F, hipStream_t s);
+
 // ---- GroupNorm ------------------------------------------------------------------------------------------------------
 // partial sums -> scale/shift table (as gn_finalize) plus (mean, rstd) per (sample, group)
 hipError_t launch_gn_stats(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C, double count,
@@ -49,7 +60,8 @@ hipError_t launch_nchw_chansum(const float* x, float* db, int B, int C, int64_t 
 // ---- weight gradients -------------------------------------------------------------------------------------------------
 struct WgArgs {
     const void* x;            // A source NHWC T [B][Hin][Win][Cin] (the forward conv's raw input)
-    const float2* gn_ab;      // forward prologue GroupNorm (+SiLU) to redo on the fly, or null
+    const float2* gn_ab;      // forward prologue GroupNorm (+SiLU when `silu`) to redo on the fly, or null
+    int silu;
     const void* dy;           // NHWC T [B][Hout][Wout][Cout]
     float* part;              // [nsplit][taps_w][Cout][Cin] fp32 partial sums
     int B, Hin, Win, Cin, Hout, Wout, Cout, MH, MW, OS, npar, ntaps, taps_w, n_ty, n_tx, nsplit;
@@ -62,13 +74,12 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout);
 hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s);
 hipError_t wgrad_prepare();
 // grads[(o*I + i)*taps + t] (Conv2d) or grads[(i*O + o)*taps + t] (ConvTranspose2d) += sum over splits
-hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int transposed, float* grad, hipStream_t s);
-// stem / head weights: G[c][ch][t] = sum_q X[q][c] * img[ch][q + sgn * d_t]; X NHWC T (optionally GroupNorm-ed, no SiLU), img NCHW fp32
-int wsmall_blocks(int H);
-hipError_t launch_wgrad_small(int dtype, const void* xn, const float2* gn_ab, const float* img, int img_ch, int sgn, float* part,
-                              int B, int H, int W, int C, hipStream_t s);
-hipError_t launch_wsmall_reduce(const float* part, int nblk, int C, int img_ch, int head, float* grad, hipStream_t s);
-
+// Ov / Iv: the rows / columns of the partial tiles that exist in the parameter (padding channels are dropped)
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed, float* grad, hipStream_t s);
+// layout changes feeding the generic kernel for the stem / head weights: im2col of the NCHW fp32 image (k = ci*9 + tap, 32 columns)
+// and NCHW fp32 -> NHWC T with the channels padded to Cp
+hipError_t launch_im2col27(int dtype, const float* x, void* dst, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_nchw_to_nhwc_pad(int dtype, const float* x, void* dst, int B, int C, int Cp, int64_t hw, hipStream_t s);
 // ---- conditioning (small fp32 linears) ----------------------------------------------------------------------------------
 hipError_t launch_tlinear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, float* u, int R, int K, int N,
                               int silu, hipStream_t s);

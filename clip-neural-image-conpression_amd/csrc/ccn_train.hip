@@ -64,7 +64,7 @@ const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd",
                                         "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
 struct Mark { int fam; hipEvent_t ev; double flops; };
 
-struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, scr_small = 0, tensors = 0, total = 0; };
+struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; };
 
 }  // namespace
 
@@ -81,6 +81,8 @@ struct ccn_trainer_s {
     std::vector<Layer> layers;
     int F = 0;
     float* zero_bias = nullptr;
+    PackDesc* pack_descs = nullptr; int n_pack = 0;
+    LinDesc* lin_descs = nullptr; int n_lin = 0, max_lin_n = 0;
     std::vector<void*> allocs;
     std::map<std::string, ShapeInfo> shapes;
     // profiling (ccn_train_profile_*): an event before every group of launches; the time up to the next event is the group's
@@ -232,7 +234,7 @@ struct Walk {
     hipStream_t st;
     const float* P; float* Gd;            // flat parameters / gradients
     ShapeInfo need;                       // scratch maxima seen by this walk
-    float *scr_wg = nullptr, *scr_col = nullptr, *scr_small = nullptr; float2 *scr_gn = nullptr, *scr_film = nullptr;
+    float *scr_wg = nullptr, *scr_col = nullptr; float2 *scr_gn = nullptr, *scr_film = nullptr;
     std::string err;
     // conditioning buffers
     float *temb = nullptr, *u0 = nullptr, *t1 = nullptr, *tp = nullptr, *uz = nullptr, *zpv = nullptr, *hv = nullptr, *film = nullptr;
@@ -266,7 +268,7 @@ struct Walk {
     void place_scratch(const ShapeInfo& si)
     {
         scr_wg = (float*)take(si.scr_wg); scr_gn = (float2*)take(si.scr_gn); scr_film = (float2*)take(si.scr_film);
-        scr_col = (float*)take(si.scr_col); scr_small = (float*)take(si.scr_small);
+        scr_col = (float*)take(si.scr_col);
     }
 
     // ---- forward pieces --------------------------------------------------------------------------------------------------
@@ -362,20 +364,14 @@ struct Walk {
         if (!ok(launch_tlinear_fwd(t1, 4 * td, par(tr->tp2.pw), par(tr->tp2.pb), tp, td, nullptr, B, 4 * td, td, 0, st), "time_proj.2")) return false;
         if (!ok(launch_tlinear_fwd(z, c.z_dim, par(tr->zp.pw), par(tr->zp.pb), zpv, td, uz, B, c.z_dim, td, 1, st), "z_proj")) return false;
         if (!ok(launch_add2(hv, tp, zpv, (int64_t)B * td, st), "h")) return false;
-        for (const TRes& r : tr->res) {
-            if (!ok(launch_tlinear_fwd(hv, td, par(r.fs.pw), par(r.fs.pb), film + r.film_off, tr->F, nullptr, B, td, r.C, 0, st), "film")) return false;
-            if (!ok(launch_tlinear_fwd(hv, td, par(r.fh.pw), par(r.fh.pb), film + r.film_off + r.C, tr->F, nullptr, B, td, r.C, 0, st), "film")) return false;
-        }
-        return true;
+        return ok(launch_film_group_fwd(P, tr->lin_descs, tr->n_lin, tr->max_lin_n, hv, film, B, td, tr->F, st), "film");
     }
 
     bool forward(const float* x_t, const float* z, const int64_t* t, float* eps)
     {
         if (launch) {
-            if (!pack(tr->stem) || !pack(tr->head)) return false;
-            for (const TRes& r : tr->res) if (!pack(r.c1) || !pack(r.c2)) return false;
-            for (const TConvW& w : tr->downs) if (!pack(w)) return false;
-            for (const TConvW& w : tr->ups) if (!pack(w)) return false;
+            mark(TF_PACK);
+            if (!ok(launch_pack_group(tr->cfg.dtype, P, tr->pack_descs, tr->n_pack, st), "pack")) return false;
         }
         if (!conditioning(z, t)) return false;
         TT x; std::vector<TT> skips;
@@ -438,27 +434,33 @@ struct Walk {
     // dW (and db) of a conv: A = act(GN(x)) redone on the fly, dY given
     bool conv_wgrad(const TConvW& w, const TT& xin, const float2* gn_ab, const void* dy, int Hdy, int Wdy, bool bias_done = false)
     {
-        const Geom g = geom_of(w.kind, xin.H, xin.W, false);
-        WgArgs a{};
-        a.x = xin.p; a.gn_ab = gn_ab; a.dy = dy; a.part = scr_wg;
-        a.B = B; a.Hin = xin.H; a.Win = xin.W; a.Cin = w.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = w.Cout;
-        a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps; a.taps_w = w.kind == KIND_CT4 ? 16 : 9;
-        a.n_ty = ceil_div(g.MH, 4); a.n_tx = ceil_div(g.MW, 32);
-        a.nsplit = wgrad_nsplit(tr->cfg.dtype, w.kind, B, g.MH, g.MW, w.Cin, w.Cout);
-        fill_taps(a.tapinfo, w.kind, false);
-        want(need.scr_wg, (size_t)a.nsplit * a.taps_w * w.Cout * w.Cin * 4);
+        if (!wgrad_generic(w.kind, xin.p, xin.H, xin.W, w.Cin, w.Cin, gn_ab, 1, dy, w.Cout, w.Cout, grad_or_null(w.pw))) return false;
         const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, Hdy * Wdy, w.Cout);
         want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
-        (void)Hdy; (void)Wdy;
-        if (!launch) return true;
-        mark(TF_WGRAD, 2.0 * B * g.Hout * g.Wout * (double)w.Cout * (w.kind == KIND_CT4 ? 4 : 9) * w.Cin);
-        if (!ok(launch_wgrad(tr->cfg.dtype, w.kind, a, st), "wgrad")) return false;
-        mark(TF_WGRAD_REDUCE);
-        if (!ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, w.Cout, w.Cin, w.kind == KIND_CT4 ? 1 : 0, grad(w.pw), st), "wgrad_reduce")) return false;
-        if (bias_done) return true;
+        if (!launch || bias_done) return true;
         mark(TF_BIAS);
         if (g_sum_rows > 0) return ok(launch_colsum_from_pairs(scr_film, g_sum_rows, w.Cout, grad(w.pb), st), "bias_grad");
-        return ok(launch_colsum(tr->cfg.dtype, dy, scr_col, grad(w.pb), B, g.Hout * g.Wout, w.Cout, st), "bias_grad");
+        return ok(launch_colsum(tr->cfg.dtype, dy, scr_col, grad(w.pb), B, Hdy * Wdy, w.Cout, st), "bias_grad");
+    }
+    float* grad_or_null(int i) const { return Gd ? grad(i) : nullptr; }
+    // kind: the forward conv's family (KIND_STEM = 1x1 on an im2col'ed input); Cin / Cout as stored (multiples of 8), Civ / Cov the
+    // channels that exist in the parameter
+    bool wgrad_generic(int kind, const void* x, int Hin, int Win, int Cin, int Civ, const float2* gn_ab, int silu, const void* dy, int Cout, int Cov, float* gdst)
+    {
+        const Geom g = geom_of(kind, Hin, Win, false);
+        WgArgs a{};
+        a.x = x; a.gn_ab = gn_ab; a.silu = silu; a.dy = dy; a.part = scr_wg;
+        a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = Cout;
+        a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps; a.taps_w = kind == KIND_CT4 ? 16 : (kind == KIND_STEM ? 1 : 9);
+        a.n_ty = ceil_div(g.MH, 4); a.n_tx = ceil_div(g.MW, 32);
+        a.nsplit = wgrad_nsplit(tr->cfg.dtype, kind, B, g.MH, g.MW, Cin, Cout);
+        fill_taps(a.tapinfo, kind, false);
+        want(need.scr_wg, (size_t)a.nsplit * a.taps_w * Cout * Cin * 4);
+        if (!launch) return true;
+        mark(TF_WGRAD, 2.0 * B * g.Hout * g.Wout * (double)Cov * (kind == KIND_CT4 ? 4 : (kind == KIND_STEM ? 1 : 9)) * Civ);
+        if (!ok(launch_wgrad(tr->cfg.dtype, kind, a, st), "wgrad")) return false;
+        mark(TF_WGRAD_REDUCE);
+        return ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, Cout, Cin, Cov, Civ, kind == KIND_CT4 ? 1 : 0, gdst, st), "wgrad_reduce");
     }
     // GroupNorm(+SiLU) backward of the norm reading tensor `x`: dA -> out (may alias dA)
     bool gn_bwd(const TT& x, const TNorm& n, const float2* ab, const float2* stats, const void* dA, void* out, bool silu, const void* addend,
@@ -505,14 +507,14 @@ struct Walk {
                 case L_HEAD: {
                     const TConvW& w = tr->head;
                     const TT& u = head_in;
-                    // out.weight / out.bias
-                    want(need.scr_small, (size_t)B * wsmall_blocks(H) * u.C * 27 * 4);
+                    // out.weight: the generic kernel on d eps as an NHWC tensor (channels padded to 8), A = out_norm(u) without SiLU
+                    void* de = take((size_t)B * H * W * 8 * tr->elem);
                     if (launch) {
                         mark(TF_SMALL);
-                        if (!ok(launch_wgrad_small(dt, u.p, ab_o, d_eps, c.img_ch, -1, scr_small, B, H, W, u.C, st), "head_wgrad")) return false;
-                        if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), u.C, c.img_ch, 1, grad(w.pw), st), "head_wgrad_reduce")) return false;
+                        if (!ok(launch_nchw_to_nhwc_pad(dt, d_eps, de, B, c.img_ch, 8, (int64_t)H * W, st), "head_deps_layout")) return false;
                         if (!ok(launch_nchw_chansum(d_eps, grad(w.pb), B, c.img_ch, (int64_t)H * W, st), "head_bias")) return false;
                     }
+                    if (!wgrad_generic(KIND_C3S1, u.p, H, W, u.C, u.C, ab_o, 0, de, 8, c.img_ch, grad_or_null(w.pw))) return false;
                     g = new_tensor(u.C, H, W);
                     if (!conv_dgrad(w, d_eps, H, W, g.p, nullptr)) return false;
                     if (!gn_bwd(u, tr->out_norm, ab_o, st_o, g.p, g.p, false, nullptr, -1)) return false;
@@ -555,16 +557,18 @@ struct Walk {
                 }
                 case L_STEM: {
                     const TConvW& w = tr->stem;
-                    want(need.scr_small, (size_t)B * wsmall_blocks(H) * w.Cout * 27 * 4);
+                    // in_conv.weight: 1x1 weight gradient against the im2col of the image (27 of 32 columns)
                     const GnBwdGeom gg = gn_bwd_geom(dt, H * W, w.Cout);
                     want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
+                    void* col = take((size_t)B * H * W * 32 * tr->elem);
                     if (launch) {
                         mark(TF_SMALL);
-                        if (!ok(launch_wgrad_small(dt, g.p, nullptr, x_t, c.img_ch, +1, scr_small, B, H, W, w.Cout, st), "stem_wgrad")) return false;
-                        if (!ok(launch_wsmall_reduce(scr_small, B * wsmall_blocks(H), w.Cout, c.img_ch, 0, grad(w.pw), st), "stem_wgrad_reduce")) return false;
+                        if (!ok(launch_im2col27(dt, x_t, col, B, c.img_ch, H, W, st), "stem_im2col")) return false;
+                        mark(TF_BIAS);
                         if (g_sum_rows > 0) { if (!ok(launch_colsum_from_pairs(scr_film, g_sum_rows, w.Cout, grad(w.pb), st), "stem_bias")) return false; }
                         else if (!ok(launch_colsum(dt, g.p, scr_col, grad(w.pb), B, H * W, w.Cout, st), "stem_bias")) return false;
                     }
+                    if (!wgrad_generic(KIND_STEM, col, H, W, 32, c.img_ch * 9, nullptr, 0, g.p, w.Cout, w.Cout, grad_or_null(w.pw))) return false;
                     break;
                 }
             }
@@ -572,12 +576,9 @@ struct Walk {
         // conditioning: film_r = h W_r^T + b_r for every block; h = time_proj(temb(t)) + z_proj(z)
         if (!launch) return true;
         mark(TF_COND);
-        bool first = true;
-        for (const TRes& r : tr->res) {
-            if (!lin_bwd(r.fs, dfilm + r.film_off, tr->F, hv, td, dh, td, first ? 0 : 1)) return false;
-            first = false;
-            if (!lin_bwd(r.fh, dfilm + r.film_off + r.C, tr->F, hv, td, dh, td, 1)) return false;
-        }
+        if (hipMemsetAsync(dh, 0, (size_t)B * td * 4, st) != hipSuccess) { err = "hipMemsetAsync failed"; return false; }
+        if (!ok(launch_film_group_dw(Gd, tr->lin_descs, tr->n_lin, tr->max_lin_n, dfilm, hv, B, td, tr->F, st), "film_dw")) return false;
+        if (!ok(launch_film_group_dx(P, tr->lin_descs, tr->n_lin, dfilm, dh, B, td, tr->F, st), "film_dx")) return false;
         if (!lin_bwd(tr->tp2, dh, td, t1, 4 * td, dt1, 4 * td, 0)) return false;
         if (!ok(launch_silu_bwd(du0, dt1, u0, (int64_t)B * 4 * td, st), "silu_bwd")) return false;
         if (!lin_bwd(tr->tp0, du0, 4 * td, temb, td, nullptr, 0, 0)) return false;
@@ -601,7 +602,7 @@ int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
     ShapeInfo si = w.need;
     si.tensors = align_up(w.off, 256);
     si.total = si.tensors + align_up(si.scr_wg, 256) + align_up(si.scr_gn, 256) + align_up(si.scr_film, 256) + align_up(si.scr_col, 256) +
-               align_up(si.scr_small, 256) + 5 * 256;
+               5 * 256;
     tr->shapes[key] = si;
     *out = si;
     return CCN_OK;
@@ -637,6 +638,44 @@ int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
     good = good && alloc_dev(tr, (size_t)(maxc + 256) * 4, &zb, err);
     if (good && hipMemset(zb, 0, (size_t)(maxc + 256) * 4) != hipSuccess) { good = false; err = "hipMemset failed"; }
     if (good && (conv_prepare() != hipSuccess || wgrad_prepare() != hipSuccess)) { good = false; err = "kernel attribute setup failed"; }
+    if (good) {
+        // descriptor tables of the grouped launches (offsets into the caller's flat buffers are fixed by the architecture)
+        std::vector<PackDesc> pd;
+        auto add_pack = [&](const TConvW& w) {
+            const long long src = (long long)tr->params[w.pw].off;
+            switch (w.kind) {
+                case KIND_C3S1: case KIND_C3S2:
+                    pd.push_back({src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad});
+                    pd.push_back({src, w.wd, w.kind == KIND_C3S1 ? PK_DG3S1 : PK_DG3S2, w.Cout, w.Cin, w.dtaps, w.dCout_pad, w.dCin_pad});
+                    break;
+                case KIND_CT4:
+                    pd.push_back({src, w.wf, PK_CONVT, w.Cout, w.Cin, 16, w.Cout_pad, w.Cin_pad});
+                    pd.push_back({src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad});
+                    break;
+                case KIND_STEM: pd.push_back({src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad}); break;
+                case KIND_HEAD:
+                    pd.push_back({src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad});
+                    pd.push_back({src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad});
+                    break;
+            }
+        };
+        add_pack(tr->stem); add_pack(tr->head);
+        for (const TRes& r : tr->res) { add_pack(r.c1); add_pack(r.c2); }
+        for (const TConvW& w : tr->downs) add_pack(w);
+        for (const TConvW& w : tr->ups) add_pack(w);
+        std::vector<LinDesc> ld;
+        for (const TRes& r : tr->res) {
+            ld.push_back({(long long)tr->params[r.fs.pw].off, (long long)tr->params[r.fs.pb].off, r.C, r.film_off});
+            ld.push_back({(long long)tr->params[r.fh.pw].off, (long long)tr->params[r.fh.pb].off, r.C, r.film_off + r.C});
+            if (r.C > tr->max_lin_n) tr->max_lin_n = r.C;
+        }
+        void *pdd = nullptr, *ldd = nullptr;
+        good = alloc_dev(tr, pd.size() * sizeof(PackDesc), &pdd, err) && alloc_dev(tr, ld.size() * sizeof(LinDesc), &ldd, err);
+        if (good && (hipMemcpy(pdd, pd.data(), pd.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess ||
+                     hipMemcpy(ldd, ld.data(), ld.size() * sizeof(LinDesc), hipMemcpyHostToDevice) != hipSuccess)) { good = false; err = "descriptor upload failed"; }
+        tr->pack_descs = (PackDesc*)pdd; tr->n_pack = (int)pd.size();
+        tr->lin_descs = (LinDesc*)ldd; tr->n_lin = (int)ld.size();
+    }
     if (!good) { ccn_train_destroy(tr); return tfail(CCN_EHIP, err); }
     tr->zero_bias = (float*)zb;
     *out = tr;

@@ -10,7 +10,7 @@
 //                        split over workgroups; partial sums go to scratch and are reduced in a fixed order (deterministic).
 //   gn_bwd_*             GroupNorm (+SiLU) backward in two HBM passes: per-channel sums, then the apply pass, which also folds
 //                        the residual-gradient add and the FiLM backward (scale by 1+s, sums for d scale / d shift).
-//   wgrad_small_kernel   stem / head weight gradients (3 image channels x 9 taps against C channels).
+//   im2col27 / nchw_to_nhwc_pad   layout changes that let the stem / head weights use the same weight-gradient kernel.
 //   tlinear_*            conditioning MLP / FiLM linears, fp32.
 //   adamw_kernel, mse_loss_grad
 #include "ccn_device.h"
@@ -79,6 +79,140 @@ hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, 
     return hipGetLastError();
 }
 
+// thread -> one (n, k) pair: its taps are contiguous in the reference layouts (9 or 16 floats), so the reads are whole
+// segments and the writes, one per tap plane, are coalesced across the threads' consecutive k
+template <typename T>
+__global__ void pack_group_kernel(const float* __restrict__ params, const PackDesc* __restrict__ descs)
+{
+    const PackDesc d = descs[blockIdx.y];
+    const float* w = params + d.src_off;
+    T* dst = (T*)d.dst;
+    const int O = d.O, I = d.I, Np = d.Np, Kp = d.Kp;
+    const size_t plane = (size_t)Np * Kp;
+    if (d.mode == PK_STEM || d.mode == PK_HEAD_DG) {
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+            const int k = (int)(idx % Kp), n = (int)(idx / Kp);
+            float v = 0.f;
+            if (d.mode == PK_STEM) { if (n < O && k < I * 9) v = w[(size_t)n * I * 9 + k]; }
+            else if (n < I && k < O * 9) { const int co = k / 9, tp = k - co * 9; v = w[((size_t)co * I + n) * 9 + (8 - tp)]; }
+            dst[idx] = to_elem<T>(v);
+        }
+        return;
+    }
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % Kp), n = (int)(idx / Kp);
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = 0.f;
+        switch (d.mode) {
+            case PK_CONV3:
+                if (n < O && k < I) { const float* p = w + ((size_t)n * I + k) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = p[t]; }
+                break;
+            case PK_CONVT:
+                if (n < O && k < I) { const float* p = w + ((size_t)k * O + n) * 16;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = p[t]; }
+                break;
+            case PK_DG3S1:
+                if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = p[8 - t]; }
+                break;
+            case PK_DG3S2:
+                if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = ((t >> 2) < 3 && (t & 3) < 3) ? p[(t >> 2) * 3 + (t & 3)] : 0.f; }
+                break;
+            case PK_DGT:
+                if (n < I && k < O) { const float* p = w + ((size_t)n * O + k) * 16;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = p[t]; }
+                break;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < d.taps) dst[(size_t)t * plane + idx] = to_elem<T>(v[t]);
+    }
+}
+hipError_t launch_pack_group(int dtype, const float* params, const PackDesc* descs_dev, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    if (dtype == 0) hipLaunchKernelGGL(pack_group_kernel<float>, dim3(64, n), dim3(256), 0, s, params, descs_dev);
+    else hipLaunchKernelGGL(pack_group_kernel<__bf16>, dim3(64, n), dim3(256), 0, s, params, descs_dev);
+    return hipGetLastError();
+}
+
+// ---- grouped FiLM linears ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void film_group_fwd_kernel(const float* __restrict__ params, const LinDesc* __restrict__ descs, const float* __restrict__ h,
+                                                              float* __restrict__ film, int B, int K, int F)
+{
+    const LinDesc d = descs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = blockIdx.x * 4 + wave;
+    if (n >= d.N) return;
+    const float* wrow = params + d.w_off + (size_t)n * K;
+    const float bias = params[d.b_off + n];
+    for (int r = 0; r < B; ++r) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(h[(size_t)r * K + k], wrow[k], acc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) film[(size_t)r * F + d.out_off + n] = acc + bias;
+    }
+}
+hipError_t launch_film_group_fwd(const float* params, const LinDesc* d, int n, int maxN, const float* h, float* film, int B, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(film_group_fwd_kernel, dim3((maxN + 3) / 4, n), dim3(256), 0, s, params, d, h, film, B, K, F);
+    return hipGetLastError();
+}
+__global__ void film_group_dw_kernel(float* __restrict__ grads, const LinDesc* __restrict__ descs, const float* __restrict__ dfilm, const float* __restrict__ h,
+                                     int B, int K, int F)
+{
+    const LinDesc d = descs[blockIdx.y];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)d.N * K) return;
+    const int k = (int)(idx % K), n = (int)(idx / K);
+    float acc = 0.f, sb = 0.f;
+    for (int r = 0; r < B; ++r) { const float dv = dfilm[(size_t)r * F + d.out_off + n]; acc = fmaf(dv, h[(size_t)r * K + k], acc); sb += dv; }
+    grads[d.w_off + idx] += acc;
+    if (k == 0) grads[d.b_off + n] += sb;
+}
+hipError_t launch_film_group_dw(float* grads, const LinDesc* d, int n, int maxN, const float* dfilm, const float* h, int B, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(film_group_dw_kernel, dim3((unsigned)(((size_t)maxN * K + 255) / 256), n), dim3(256), 0, s, grads, d, dfilm, h, B, K, F);
+    return hipGetLastError();
+}
+// dh[r][k] += sum_n dfilm[r][off + n] W[n][k] for every linear (dh zeroed by the caller); block = 64 k x 4 waves over n, 4 rows
+__global__ __launch_bounds__(256) void film_group_dx_kernel(const float* __restrict__ params, const LinDesc* __restrict__ descs, const float* __restrict__ dfilm,
+                                                             float* __restrict__ dh, int B, int K, int F)
+{
+    __shared__ float red[4][4][64];
+    const LinDesc d = descs[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, r0 = blockIdx.y * 4, kk = k < K ? k : K - 1;
+    const float* W = params + d.w_off;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int n = wave; n < d.N; n += 4) {
+        const float w = W[(size_t)n * K + kk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int r = r0 + j < B ? r0 + j : B - 1; acc[j] = fmaf(dfilm[(size_t)r * F + d.out_off + n], w, acc[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    if (wave == 0 && k < K)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + j < B) atomicAdd(dh + (size_t)(r0 + j) * K + k, (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]));
+}
+hipError_t launch_film_group_dx(const float* params, const LinDesc* d, int n, const float* dfilm, float* dh, int B, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(film_group_dx_kernel, dim3((K + 63) / 64, (B + 3) / 4, n), dim3(256), 0, s, params, d, dfilm, dh, B, K, F);
+    return hipGetLastError();
+}
+
 // ---- GroupNorm statistics ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float2* __restrict__ part, int G, int n_sp, int n_nt, int bn, int cpg, int C,
                                                         double count, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -128,7 +262,10 @@ GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
     int nslb = nsl <= 256 ? nsl : 256;
     while (nsl % nslb) --nslb;                                   // largest divisor of nsl that fits a workgroup
     g.nslb = nslb; g.zblocks = nsl / nslb; g.pstep = 256 / nslb;
-    g.ppb = g.pstep * 32;                                        // pixels per workgroup
+    // pixels per workgroup: at least 256 workgroups per sample (the 32-pixel level would otherwise run on 8), at most 32 passes
+    int iters = HW / (g.pstep * 256);
+    iters = iters < 1 ? 1 : (iters > 32 ? 32 : iters);
+    g.ppb = g.pstep * iters;
     g.nblk = (HW + g.ppb - 1) / g.ppb;
     return g;
 }
@@ -202,22 +339,34 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __re
                                                                const float* __restrict__ gamma, float2* __restrict__ gstat,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    __shared__ double red[4][2];
-    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // thread -> (channel of a 16-channel slab, one of 16 block lanes): coalesced 128-byte rows, fixed summation order
+    __shared__ float red[16][16][2];
+    __shared__ double mm[16][2];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
     double m1 = 0.0, m2 = 0.0;
-    for (int c = g * cpg + wave; c < (g + 1) * cpg; c += 4) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < nblk; k += 64) { const float2 v = part[((size_t)b * nblk + k) * C + c]; s1 += (double)v.x; s2 += (double)v.y; }
+    for (int c0 = g * cpg; c0 < (g + 1) * cpg; c0 += 16) {
+        const int c = c0 + cl;
+        const bool valid = c < (g + 1) * cpg;
+        float p1 = 0.f, p2 = 0.f;
+        if (valid)
+            for (int k = rl; k < nblk; k += 16) { const float2 v = part[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
+        red[rl][cl][0] = p1; red[rl][cl][1] = p2;
+        __syncthreads();
+        if (rl == 0 && valid) {
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s); s2 += __shfl_xor(s2, s); }
-        if (lane == 0) { atomicAdd(dgamma + c, (float)s2); atomicAdd(dbeta + c, (float)s1); }
-        m1 += (double)gamma[c] * s1; m2 += (double)gamma[c] * s2;
+            for (int q = 0; q < 16; ++q) { s1 += (double)red[q][cl][0]; s2 += (double)red[q][cl][1]; }
+            atomicAdd(dgamma + c, (float)s2); atomicAdd(dbeta + c, (float)s1);
+            m1 += (double)gamma[c] * s1; m2 += (double)gamma[c] * s2;
+        }
+        __syncthreads();
     }
-    if (lane == 0) { red[wave][0] = m1; red[wave][1] = m2; }
+    if (rl == 0) { mm[cl][0] = m1; mm[cl][1] = m2; }
     __syncthreads();
     if (tid == 0) {
-        m1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        m2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        m1 = 0.0; m2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { m1 += mm[q][0]; m2 += mm[q][1]; }
         gstat[bg] = make_float2((float)(m1 / count), (float)(m2 / count));
     }
 }
@@ -293,13 +442,20 @@ hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const f
 
 // d scale[b][c] = sum dF * y1, y1 = (F - shift) / (1 + scale); d shift[b][c] = sum dF   (F = y1 (1 + scale) + shift is what the
 // forward stored; a block whose 1 + scale is exactly zero has lost y1 and gets d scale = 0)
-__global__ void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int nblk, const float* __restrict__ film, int film_bstride,
-                                         float* __restrict__ dfilm, int C, float* __restrict__ dbias)
+__global__ __launch_bounds__(256) void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int nblk, const float* __restrict__ film,
+                                                                 int film_bstride, float* __restrict__ dfilm, int C, float* __restrict__ dbias)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
+    __shared__ float red[16][16][2];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl, b = blockIdx.y;
+    float p1 = 0.f, p2 = 0.f;
+    if (c < C)
+        for (int k = rl; k < nblk; k += 16) { const float2 v = fpart[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
+    red[rl][cl][0] = p1; red[rl][cl][1] = p2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) { const float2 v = fpart[((size_t)b * nblk + k) * C + c]; s1 += (double)v.x; s2 += (double)v.y; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1 += (double)red[q][cl][0]; s2 += (double)red[q][cl][1]; }
     const float sc = 1.0f + film[(size_t)b * film_bstride + c], sft = film[(size_t)b * film_bstride + C + c];
     dfilm[(size_t)b * film_bstride + c] = sc != 0.f ? (float)((s2 - (double)sft * s1) / (double)sc) : 0.f;
     dfilm[(size_t)b * film_bstride + C + c] = (float)s1;
@@ -309,7 +465,7 @@ __global__ void film_bwd_finalize_kernel(const float2* __restrict__ fpart, int n
 hipError_t launch_film_bwd_finalize(const float2* fpart, int nblk, const float* film, int film_bstride, float* dfilm, float* dbias, int B, int C,
                                     hipStream_t s)
 {
-    hipLaunchKernelGGL(film_bwd_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, fpart, nblk, film, film_bstride, dfilm, C, dbias);
+    hipLaunchKernelGGL(film_bwd_finalize_kernel, dim3((C + 15) / 16, B), dim3(256), 0, s, fpart, nblk, film, film_bstride, dfilm, C, dbias);
     return hipGetLastError();
 }
 
@@ -346,14 +502,14 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < C)
-        for (int k = rl; k < rows; k += 16) s += scratch[(size_t)k * C + c];
+        for (int k = blockIdx.y * 16 + rl; k < rows; k += 16 * gridDim.y) s += scratch[(size_t)k * C + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += (double)red[q][cl];
-        db[c] += (float)t;
+        atomicAdd(db + c, (float)t);
     }
 }
 // the same from the (sum, -) pairs the GroupNorm-backward apply pass leaves behind
@@ -363,19 +519,20 @@ __global__ __launch_bounds__(256) void colsum_pair_finalize_kernel(const float2*
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < C)
-        for (int k = rl; k < rows; k += 16) s += part[(size_t)k * C + c].x;
+        for (int k = blockIdx.y * 16 + rl; k < rows; k += 16 * gridDim.y) s += part[(size_t)k * C + c].x;
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += (double)red[q][cl];
-        db[c] += (float)t;
+        atomicAdd(db + c, (float)t);
     }
 }
 hipError_t launch_colsum_from_pairs(const float2* part, int rows, int C, float* db, hipStream_t s)
 {
-    hipLaunchKernelGGL(colsum_pair_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, rows, C, db);
+    const int chunks = rows >= 512 ? 8 : (rows >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(colsum_pair_finalize_kernel, dim3((C + 15) / 16, chunks), dim3(256), 0, s, part, rows, C, db);
     return hipGetLastError();
 }
 hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s)
@@ -385,7 +542,7 @@ hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, i
     const dim3 grid(g.nblk, B, g.zblocks);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
     else hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, scratch, B * g.nblk, C, db);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16, B * g.nblk >= 512 ? 8 : (B * g.nblk >= 64 ? 4 : 1)), dim3(256), 0, s, scratch, B * g.nblk, C, db);
     return hipGetLastError();
 }
 
@@ -418,7 +575,7 @@ hipError_t launch_nchw_chansum(const float* x, float* db, int B, int C, int64_t 
 template <int IS> struct WgGeom {
     static constexpr int ROWS = IS * 3 + 3, PITCH = IS == 1 ? 34 : 66;
 };
-template <typename T, int IS, int NTAPS, int WN, int WK>
+template <typename T, int IS, int NTAPS, int WN, int WK, bool SILU = true>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a)
 {
     constexpr int NT = 32 * WN, KT = 32 * WK, EPC = Vec16<T>::EPC;
@@ -461,7 +618,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a)
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if (cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
                     v = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
-                    if (a.gn_ab) v = gk.template apply<true>(v);
+                    if (a.gn_ab) v = gk.template apply<SILU>(v);
                 }
                 float f[EPC];
                 Vec16<T>::unpack(v, f);
@@ -521,7 +678,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p)
 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
-template <int IS, int NTAPS>
+template <int IS, int NTAPS, bool SILU = true>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a)
 {
     typedef __bf16 T;
@@ -593,7 +750,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a)
                     const int pxl = (tid >> 3) + 32 * (g0 + u);
                     if (g0 + u < NA && pxl < NPA) {
                         u32x4 v = ra[u];
-                        if (((okm >> u) & 1u) && a.gn_ab) v = gk.template apply<true>(v);
+                        if (((okm >> u) & 1u) && a.gn_ab) v = gk.template apply<SILU>(v);
                         *(u32x4*)(dstA + pxl * 64) = v;
                     }
                 }
@@ -632,31 +789,37 @@ template <int IS> static constexpr size_t wgrad_bf16_lds() { return (size_t)(2 *
 
 template <int IS, int WN, int WK> static constexpr size_t wgrad_lds() { return (size_t)(WgGeom<IS>::ROWS * WgGeom<IS>::PITCH * 32 * WK + 128 * 32 * WN) * 4; }
 typedef void (*wgrad_fn_t)(const WgArgs);
-static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt)
+static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt, bool silu = true)
 {
     if (dtype == 1) {
         *nt = 64; *kt = 64;
+        if (!silu && kind == KIND_C3S1) { *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 9, false>; }
         switch (kind) {
             case KIND_C3S2: *lds = wgrad_bf16_lds<2>(); return (wgrad_fn_t)wgrad_bf16_kernel<2, 9>;
             case KIND_CT4: *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 4>;
+            case KIND_STEM: *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 1>;      // 1x1: im2col'ed stem
             default: *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 9>;
         }
     }
+    if (!silu && kind == KIND_C3S1) { *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 9, 2, 2, false>; }
     switch (kind) {
         case KIND_C3S2: *lds = wgrad_lds<2, 4, 1>(); *nt = 128; *kt = 32; return (wgrad_fn_t)wgrad_kernel<float, 2, 9, 4, 1>;
         case KIND_CT4: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 4, 2, 2>;
+        case KIND_STEM: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 1, 2, 2>;
         default: *lds = wgrad_lds<1, 2, 2>(); *nt = 64; *kt = 64; return (wgrad_fn_t)wgrad_kernel<float, 1, 9, 2, 2>;
     }
 }
 hipError_t wgrad_prepare()
 {
-    static const int kinds[] = {KIND_C3S1, KIND_C3S2, KIND_CT4};
+    static const int kinds[] = {KIND_C3S1, KIND_C3S2, KIND_CT4, KIND_STEM};
     for (int dt = 0; dt < 2; ++dt)
         for (int kind : kinds) {
             size_t lds; int nt, kt;
-            const wgrad_fn_t fn = wgrad_pick(dt, kind, &lds, &nt, &kt);
-            hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
+            for (int silu = 0; silu < 2; ++silu) {
+                const wgrad_fn_t fn = wgrad_pick(dt, kind, &lds, &nt, &kt, silu != 0);
+                hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
         }
     return hipSuccess;
 }
@@ -675,7 +838,8 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
 hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
 {
     size_t lds; int nt, kt;
-    const wgrad_fn_t fn = wgrad_pick(dtype, kind, &lds, &nt, &kt);
+    if (a.gn_ab && !a.silu && kind != KIND_C3S1) return hipErrorInvalidValue;       // GroupNorm without SiLU only exists in front of the head
+    const wgrad_fn_t fn = wgrad_pick(dtype, kind, &lds, &nt, &kt, !a.gn_ab || a.silu != 0);
     const int epc = dtype == 0 ? 4 : 8;
     if (a.Cin % epc || a.Cout % epc) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(((a.Cin + kt - 1) / kt) * ((a.Cout + nt - 1) / nt) * a.npar * a.nsplit);
@@ -683,112 +847,77 @@ hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int taps, int O, int I, int transposed, float* __restrict__ grad)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed,
+                                    float* __restrict__ grad)
 {
     const size_t per = (size_t)taps * O * I;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(idx % I), o = (int)((idx / I) % O), t = (int)(idx / ((size_t)I * O));
+        if (i >= Iv || o >= Ov) continue;
+        // fixed order, eight loads in flight
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * per + idx];
-        const size_t dst = transposed ? ((size_t)i * O + o) * taps + t : ((size_t)o * I + i) * taps + t;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * per + idx];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; k < nsplit; ++k) s += part[(size_t)k * per + idx];
+        const size_t dst = transposed ? ((size_t)i * Ov + o) * taps + t : ((size_t)o * Iv + i) * taps + t;
         grad[dst] += s;
     }
 }
-hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int transposed, float* grad, hipStream_t s)
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed, float* grad, hipStream_t s)
 {
     const size_t per = (size_t)taps * O * I;
     const unsigned grid = (unsigned)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, taps, O, I, transposed, grad);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, taps, O, I, Ov, Iv, transposed, grad);
     return hipGetLastError();
 }
 
-// stem / head: block = (8 image rows, sample, channel block); thread -> (channel, pixel lane), 27 accumulators (img_ch <= 3)
-constexpr int WS_ROWS = 2;
-int wsmall_blocks(int H) { return (H + WS_ROWS - 1) / WS_ROWS; }
+// im2col of the NCHW fp32 image: dst[b][y][x][k], k = ci*9 + (dy+1)*3 + (dx+1) for k < C*9, zero up to 32 columns
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ xn, const float2* __restrict__ gn_ab, const float* __restrict__ img,
-                                                           int img_ch, int sgn, float* __restrict__ part, int H, int W, int C, int cb)
+__global__ void im2col27_kernel(const float* __restrict__ x, T* __restrict__ dst, int C, int H, int W)
 {
-    extern __shared__ float simg[];                                  // [img_ch][3][W + 2], then the reduction buffer
-    const int tid = threadIdx.x, b = blockIdx.y, rb = blockIdx.x;
-    const int cl = tid % cb, xl = tid / cb, lanes = 256 / cb;
-    const int c = blockIdx.z * cb + cl;
-    const bool act = xl < lanes && c < C;
-    float a = 1.f, cc = 0.f;
-    if (gn_ab && c < C) ab_of((const float*)(gn_ab + (size_t)b * C), c, a, cc);
-    float acc[27];
-#pragma unroll
-    for (int j = 0; j < 27; ++j) acc[j] = 0.f;
-    const int WP = W + 2;
-    for (int y = rb * WS_ROWS; y < min(H, (rb + 1) * WS_ROWS); ++y) {
-        __syncthreads();
-        for (int i = tid; i < img_ch * 3 * WP; i += 256) {
-            const int xx = i % WP - 1, rr = (i / WP) % 3, ch = i / (3 * WP);
-            const int yy = y + rr - 1;
-            simg[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)(b * img_ch + ch) * H + yy) * W + xx] : 0.f;
+    const int b = blockIdx.y;
+    const size_t n = (size_t)H * W * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx & 31); const size_t p = idx >> 5;
+        const int xx = (int)(p % W), yy = (int)(p / W);
+        float v = 0.f;
+        if (k < C * 9) {
+            const int ci = k / 9, t = k - ci * 9, iy = yy + t / 3 - 1, ix = xx + t % 3 - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((size_t)(b * C + ci) * H + iy) * W + ix];
         }
-        __syncthreads();
-        if (act)
-            for (int x0 = xl; x0 < W; x0 += 4 * lanes) {
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {                       // four loads in flight
-                    const int x = x0 + u * lanes;
-                    v[u] = x < W ? from_elem<T>(xn[((size_t)(b * H + y) * W + x) * C + c]) : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int x = x0 + u * lanes;
-                    if (x >= W) break;
-                    const float vv = gn_ab ? fmaf(v[u], a, cc) : v[u];
-#pragma unroll
-                    for (int j = 0; j < 27; ++j) {
-                        const int ch = j / 9, t = j % 9, dy = t / 3 - 1, dx = t % 3 - 1;
-                        if (ch < img_ch) acc[j] = fmaf(vv, simg[(ch * 3 + 1 + sgn * dy) * WP + x + 1 + sgn * dx], acc[j]);
-                    }
-                }
-            }
-    }
-    __syncthreads();
-    float* red = simg;                                               // [256][27]
-#pragma unroll
-    for (int j = 0; j < 27; ++j) red[tid * 27 + j] = acc[j];
-    __syncthreads();
-    if (xl == 0 && c < C) {
-        for (int q = 1; q < lanes; ++q)
-#pragma unroll
-            for (int j = 0; j < 27; ++j) acc[j] += red[(q * cb + cl) * 27 + j];
-        float* o = part + (((size_t)b * gridDim.x + rb) * C + c) * 27;
-#pragma unroll
-        for (int j = 0; j < 27; ++j) o[j] = acc[j];
+        dst[(size_t)b * n + idx] = to_elem<T>(v);
     }
 }
-hipError_t launch_wgrad_small(int dtype, const void* xn, const float2* gn_ab, const float* img, int img_ch, int sgn, float* part, int B, int H,
-                              int W, int C, hipStream_t s)
+hipError_t launch_im2col27(int dtype, const float* x, void* dst, int B, int C, int H, int W, hipStream_t s)
 {
-    if (img_ch > 3 || W > 2048) return hipErrorInvalidValue;
-    const int cb = C < 256 ? C : 256;
-    const dim3 grid(wsmall_blocks(H), B, (C + cb - 1) / cb);
-    size_t lds = (size_t)img_ch * 3 * (W + 2) * 4;
-    if (lds < 256 * 27 * 4) lds = 256 * 27 * 4;
-    if (dtype == 0) hipLaunchKernelGGL(wgrad_small_kernel<float>, grid, dim3(256), lds, s, (const float*)xn, gn_ab, img, img_ch, sgn, part, H, W, C, cb);
-    else hipLaunchKernelGGL(wgrad_small_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)xn, gn_ab, img, img_ch, sgn, part, H, W, C, cb);
+    if (C * 9 > 32) return hipErrorInvalidValue;
+    const size_t n = (size_t)H * W * 32;
+    const dim3 grid((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), B);
+    if (dtype == 0) hipLaunchKernelGGL(im2col27_kernel<float>, grid, dim3(256), 0, s, x, (float*)dst, C, H, W);
+    else hipLaunchKernelGGL(im2col27_kernel<__bf16>, grid, dim3(256), 0, s, x, (__bf16*)dst, C, H, W);
     return hipGetLastError();
 }
-// part [nblk][C][27] -> stem: grad[(c*img_ch + ch)*9 + t]; head: grad[(ch*C + c)*9 + t]
-__global__ void wsmall_reduce_kernel(const float* __restrict__ part, int nblk, int C, int img_ch, int head, float* __restrict__ grad)
+template <typename T>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, T* __restrict__ dst, int C, int Cp, int64_t hw)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * 27) return;
-    const int c = idx / 27, j = idx % 27, ch = j / 9, t = j % 9;
-    if (ch >= img_ch) return;
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += (double)part[(size_t)k * C * 27 + idx];
-    grad[head ? ((size_t)ch * C + c) * 9 + t : ((size_t)c * img_ch + ch) * 9 + t] += (float)s;
+    const int b = blockIdx.y;
+    const int64_t n = hw * Cp;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cp); const int64_t p = idx / Cp;
+        dst[(size_t)b * n + idx] = to_elem<T>(c < C ? x[((size_t)b * C + c) * hw + p] : 0.f);
+    }
 }
-hipError_t launch_wsmall_reduce(const float* part, int nblk, int C, int img_ch, int head, float* grad, hipStream_t s)
+hipError_t launch_nchw_to_nhwc_pad(int dtype, const float* x, void* dst, int B, int C, int Cp, int64_t hw, hipStream_t s)
 {
-    hipLaunchKernelGGL(wsmall_reduce_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, s, part, nblk, C, img_ch, head, grad);
+    const int64_t n = hw * Cp;
+    const dim3 grid((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), B);
+    if (dtype == 0) hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<float>, grid, dim3(256), 0, s, x, (float*)dst, C, Cp, hw);
+    else hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<__bf16>, grid, dim3(256), 0, s, x, (__bf16*)dst, C, Cp, hw);
     return hipGetLastError();
 }
 
