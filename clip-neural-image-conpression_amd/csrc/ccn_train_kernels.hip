@@ -305,16 +305,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
     const int pend = min(HW, (blk + 1) * ppb);
     if (act)
-        for (int p = blk * ppb + pp; p < pend; p += pstep) {
-            float xv[8], dv[8];
-            const size_t off = ((size_t)b * HW + p) * C + ch0;
-            Chunk<T>::load(x + off, xv); Chunk<T>::load(dA + off, dv);
+        for (int p0 = blk * ppb + pp; p0 < pend; p0 += 4 * pstep) {       // four pixels' loads in flight
+            float xv[4][8], dv[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float da = dv[e];
-                if (silu) da *= dsilu<T>(fmaf(xv[e], a[e], c[e]));
-                const float xh = (xv[e] - mu[e]) * rs[e];
-                s1[e] += da; s2[e] = fmaf(da, xh, s2[e]);
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * pstep;
+                if (p < pend) { const size_t off = ((size_t)b * HW + p) * C + ch0; Chunk<T>::load(x + off, xv[u]); Chunk<T>::load(dA + off, dv[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u * pstep >= pend) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float da = dv[u][e];
+                    if (silu) da *= dsilu<T>(fmaf(xv[u][e], a[e], c[e]));
+                    const float xh = (xv[u][e] - mu[e]) * rs[e];
+                    s1[e] += da; s2[e] = fmaf(da, xh, s2[e]);
+                }
             }
         }
     block_reduce16(sh, tid, sl, pp, nslb, pstep, s1, s2);
@@ -335,27 +342,29 @@ hipError_t launch_gn_bwd_reduce(int dtype, const void* x, const void* dA, const 
     return hipGetLastError();
 }
 
+template <int CL>
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, int cpg, int G, double count,
                                                                const float* __restrict__ gamma, float2* __restrict__ gstat,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    // thread -> (channel of a 16-channel slab, one of 16 block lanes): coalesced 128-byte rows, fixed summation order
-    __shared__ float red[16][16][2];
-    __shared__ double mm[16][2];
-    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+    // thread -> (channel of a CL-channel slab, one of 256/CL block lanes): coalesced rows, fixed summation order
+    constexpr int RL = 256 / CL;
+    __shared__ float red[RL][CL][2];
+    __shared__ double mm[CL][2];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x, cl = tid % CL, rl = tid / CL;
     double m1 = 0.0, m2 = 0.0;
-    for (int c0 = g * cpg; c0 < (g + 1) * cpg; c0 += 16) {
+    for (int c0 = g * cpg; c0 < (g + 1) * cpg; c0 += CL) {
         const int c = c0 + cl;
         const bool valid = c < (g + 1) * cpg;
         float p1 = 0.f, p2 = 0.f;
         if (valid)
-            for (int k = rl; k < nblk; k += 16) { const float2 v = part[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
+            for (int k = rl; k < nblk; k += RL) { const float2 v = part[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
         red[rl][cl][0] = p1; red[rl][cl][1] = p2;
         __syncthreads();
         if (rl == 0 && valid) {
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { s1 += (double)red[q][cl][0]; s2 += (double)red[q][cl][1]; }
+            for (int q = 0; q < RL; ++q) { s1 += (double)red[q][cl][0]; s2 += (double)red[q][cl][1]; }
             atomicAdd(dgamma + c, (float)s2); atomicAdd(dbeta + c, (float)s1);
             m1 += (double)gamma[c] * s1; m2 += (double)gamma[c] * s2;
         }
@@ -365,15 +374,16 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __re
     __syncthreads();
     if (tid == 0) {
         m1 = 0.0; m2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { m1 += mm[q][0]; m2 += mm[q][1]; }
+        for (int q = 0; q < CL; ++q) { m1 += mm[q][0]; m2 += mm[q][1]; }
         gstat[bg] = make_float2((float)(m1 / count), (float)(m2 / count));
     }
 }
 hipError_t launch_gn_bwd_finalize(const float2* part, int nblk, int B, int C, int cpg, int G, double count, const float* gamma, float2* gstat,
                                   float* dgamma, float* dbeta, hipStream_t s)
 {
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G), dim3(256), 0, s, part, nblk, C, cpg, G, count, gamma, gstat, dgamma, dbeta);
+    if (cpg >= 64) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(B * G), dim3(256), 0, s, part, nblk, C, cpg, G, count, gamma, gstat, dgamma, dbeta);
+    else if (cpg >= 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<32>, dim3(B * G), dim3(256), 0, s, part, nblk, C, cpg, G, count, gamma, gstat, dgamma, dbeta);
+    else hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3(B * G), dim3(256), 0, s, part, nblk, C, cpg, G, count, gamma, gstat, dgamma, dbeta);
     return hipGetLastError();
 }
 
@@ -402,23 +412,35 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     const int pend = min(HW, (blk + 1) * ppb);
     if (act)
-        for (int p = blk * ppb + pp; p < pend; p += pstep) {
-            float xv[8], dv[8], rv[8], ov[8];
-            const size_t off = ((size_t)b * HW + p) * C + ch0;
-            Chunk<T>::load(x + off, xv); Chunk<T>::load(dA + off, dv);
-            if (addend) Chunk<T>::load(addend + off, rv);
+        for (int p0 = blk * ppb + pp; p0 < pend; p0 += 2 * pstep) {       // two pixels' loads in flight
+            float xv[2][8], dv[2][8], rv[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float da = dv[e];
-                if (silu) da *= dsilu<T>(fmaf(xv[e], a[e], c[e]));
-                const float xh = (xv[e] - mu[e]) * rs[e];
-                const float dx = a[e] * da - rs[e] * fmaf(xh, m2[e], m1[e]);
-                float o = dx * fs[e];
-                if (addend) o += rv[e];
-                ov[e] = o;
-                s1[e] += film ? dx : o; s2[e] = fmaf(dx, xv[e], s2[e]);
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + u * pstep;
+                if (p < pend) {
+                    const size_t off = ((size_t)b * HW + p) * C + ch0;
+                    Chunk<T>::load(x + off, xv[u]); Chunk<T>::load(dA + off, dv[u]);
+                    if (addend) Chunk<T>::load(addend + off, rv[u]);
+                }
             }
-            Chunk<T>::store(out + off, ov);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + u * pstep;
+                if (p >= pend) break;
+                float ov[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float da = dv[u][e];
+                    if (silu) da *= dsilu<T>(fmaf(xv[u][e], a[e], c[e]));
+                    const float xh = (xv[u][e] - mu[e]) * rs[e];
+                    const float dx = a[e] * da - rs[e] * fmaf(xh, m2[e], m1[e]);
+                    float o = dx * fs[e];
+                    if (addend) o += rv[u][e];
+                    ov[e] = o;
+                    s1[e] += film ? dx : o; s2[e] = fmaf(dx, xv[u][e], s2[e]);
+                }
+                Chunk<T>::store(out + ((size_t)b * HW + p) * C + ch0, ov);
+            }
         }
     if (!fpart) return;
     block_reduce16(sh, tid, sl, pp, nslb, pstep, s1, s2);
