@@ -65,6 +65,7 @@ struct WgArgs {
     const void* dy;           // NHWC T [B][Hout][Wout][Cout]
     float* part;              // [nsplit][taps_w][Cout][Cin] fp32 partial sums
     int B, Hin, Win, Cin, Hout, Wout, Cout, MH, MW, OS, npar, ntaps, taps_w, n_ty, n_tx, nsplit;
+    int dbg;                // timing ablations (CCN_WG_DBG): 1 producers idle after the first tile, 2 consumers skip the MFMA loop, 4 no partial stores
     int tapinfo[16];        // as ConvArgs::tapinfo
     __host__ __device__ int tapinfo_dy(int i) const { return (tapinfo[i] & 3) - 1; }
     __host__ __device__ int tapinfo_dx(int i) const { return ((tapinfo[i] >> 2) & 3) - 1; }

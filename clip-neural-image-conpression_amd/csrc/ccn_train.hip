@@ -59,8 +59,8 @@ struct TT {                                     // an NHWC activation and the pa
     float2* part = nullptr; int n_sp = 0, n_nt = 0, bn = 0;
 };
 
-enum { TF_PACK = 0, TF_COND, TF_CONV_FWD, TF_GN_STATS, TF_CONV_DGRAD, TF_WGRAD, TF_WGRAD_REDUCE, TF_BIAS, TF_GN_BWD, TF_SMALL, TF_COUNT };
-const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd", "conv_forward", "gn_stats", "conv_data_grad", "conv_weight_grad",
+enum { TF_PACK = 0, TF_COND, TF_CONV_FWD, TF_GN_STATS, TF_PREACT, TF_CONV_DGRAD, TF_WGRAD, TF_WGRAD_REDUCE, TF_BIAS, TF_GN_BWD, TF_SMALL, TF_COUNT };
+const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd", "conv_forward", "gn_stats", "gn_silu_prepass", "conv_data_grad", "conv_weight_grad",
                                         "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
 struct Mark { int fam; hipEvent_t ev; double flops; };
 
@@ -240,7 +240,7 @@ struct Walk {
     float *temb = nullptr, *u0 = nullptr, *t1 = nullptr, *tp = nullptr, *uz = nullptr, *zpv = nullptr, *hv = nullptr, *film = nullptr;
     float *dfilm = nullptr, *dh = nullptr, *dt1 = nullptr, *du0 = nullptr, *duz = nullptr;
     // saved by the forward walk
-    struct ResSave { TT x, y, o; float2 *ab1, *st1, *ab2, *st2; };
+    struct ResSave { TT x, y, o, xa, ya; bool pre = false; float2 *ab1, *st1, *ab2, *st2; };
     std::vector<ResSave> rs;
     TT stem_out; std::vector<TT> down_in, down_out, up_in, up_out;
     TT head_in; float2 *ab_o = nullptr, *st_o = nullptr;
@@ -340,6 +340,12 @@ struct Walk {
         return run_conv(TF_CONV_DGRAD, w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
                         nullptr, dx, nullptr, nullptr, res, false, nullptr);
     }
+    bool preact(const TT& t, const float2* ab, const TT& out)
+    {
+        if (!launch) return true;
+        mark(TF_PREACT);
+        return ok(launch_gn_act(tr->cfg.dtype, t.p, ab, out.p, B, t.H * t.W, t.C, st), "gn_act");
+    }
     bool gn_fwd(const TT& t, const TNorm& n, float2*& ab, float2*& stats)
     {
         const int G = groups_for(t.C), cpg = t.C / G;
@@ -386,13 +392,21 @@ struct Walk {
                 }
                 case L_RES: {
                     const TRes& r = tr->res[L.idx];
+                    // The activated tensors SiLU(GN(.)) are written once by a pre-pass and kept: the forward conv AND the weight-gradient
+                    // kernel then stage plain copies.  Redoing the transform while staging costs both of them VALU issue slots next to
+                    // their MFMAs (per pixel tile the weight-gradient kernel spent more cycles in exp/rcp than in MFMAs); the pre-pass is
+                    // one HBM-bound read + write per norm.  Layers the pre-pass kernel cannot take keep the fused prologue.
+                    static const bool no_pre = getenv("CCN_TRAIN_NO_PREACT") != nullptr;       // A/B switch
                     ResSave s; s.x = x;
+                    s.pre = !no_pre && r.C / (tr->elem == 2 ? 8 : 4) <= 256;
                     if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;
+                    if (s.pre) { s.xa = new_tensor(r.C, x.H, x.W); if (!preact(x, s.ab1, s.xa)) return false; }
                     s.y = new_tensor(r.C, x.H, x.W);
-                    if (!conv_fwd(r.c1, x, s.y, s.ab1, film ? film + r.film_off : nullptr, nullptr, true)) return false;
+                    if (!conv_fwd(r.c1, s.pre ? s.xa : x, s.y, s.pre ? nullptr : s.ab1, film ? film + r.film_off : nullptr, nullptr, true)) return false;
                     if (!gn_fwd(s.y, r.n2, s.ab2, s.st2)) return false;
+                    if (s.pre) { s.ya = new_tensor(r.C, x.H, x.W); if (!preact(s.y, s.ab2, s.ya)) return false; }
                     s.o = new_tensor(r.C, x.H, x.W);
-                    if (!conv_fwd(r.c2, s.y, s.o, s.ab2, nullptr, &x, true)) return false;
+                    if (!conv_fwd(r.c2, s.pre ? s.ya : s.y, s.o, s.pre ? nullptr : s.ab2, nullptr, &x, true)) return false;
                     rs.push_back(s);
                     x = s.o;
                     break;
@@ -544,11 +558,11 @@ struct Walk {
                     const TRes& r = tr->res[L.idx];
                     const ResSave& s = rs[ri]; --ri;
                     // out = x + conv2(A2), A2 = silu(gn2(F)), F = film(conv1(A1)), A1 = silu(gn1(x))
-                    if (!conv_wgrad(r.c2, s.y, s.ab2, g.p, g.H, g.W)) return false;
+                    if (!conv_wgrad(r.c2, s.pre ? s.ya : s.y, s.pre ? nullptr : s.ab2, g.p, g.H, g.W)) return false;
                     TT g1 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c2, g.p, g.H, g.W, g1.p, nullptr)) return false;
                     if (!gn_bwd(s.y, r.n2, s.ab2, s.st2, g1.p, g1.p, true, nullptr, r.film_off, launch ? grad(r.c1.pb) : nullptr)) return false;
-                    if (!conv_wgrad(r.c1, s.x, s.ab1, g1.p, g.H, g.W, true)) return false;
+                    if (!conv_wgrad(r.c1, s.pre ? s.xa : s.x, s.pre ? nullptr : s.ab1, g1.p, g.H, g.W, true)) return false;
                     TT g2 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c1, g1.p, g.H, g.W, g2.p, nullptr)) return false;
                     if (!gn_bwd(s.x, r.n1, s.ab1, s.st1, g2.p, g2.p, true, g.p, -1)) return false;

@@ -807,6 +807,160 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a)
         }
     }
 }
+// Warp-specialised form for the stride-1 kinds: waves 0-3 only run the transposed reads + MFMAs, waves 4-7 stage the NEXT pixel
+// tile into the other LDS buffer (global loads for tile j+2 are issued into registers while tile j+1 is transformed and written), one
+// workgroup barrier per tile.  The single-role kernel above spends ~60 % of a tile's time in its staging phase.
+template <int NTAPS, bool SILU>
+__global__ __launch_bounds__(512) void wgrad_bf16_ws_kernel(const WgArgs a)
+{
+    typedef __bf16 T;
+    constexpr int ROWS = WgGeom<1>::ROWS, PITCH = WgGeom<1>::PITCH, NPA = ROWS * PITCH, NA = (NPA + 31) / 32;
+    constexpr int A_BYTES = 2 * NPA * 64, D_BYTES = 2 * 128 * 64, BUF = A_BYTES + D_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_kt = (a.Cin + 63) / 64, n_nt = (a.Cout + 63) / 64;
+    // XCD-aware mapping: workgroup i runs on XCD i % 8 (round-robin dispatch) and every XCD has its own L2; the (Cout, Cin, parity)
+    // groups of one pixel split read the same pixels, so they are given to the same XCD (nsplit is a multiple of 8 or the
+    // plain order is used)
+    int bid = blockIdx.x;
+    const int ngrp = n_kt * n_nt * a.npar;
+    if ((a.nsplit & 7) == 0) { const int xcd = bid & 7, idx = bid >> 3; bid = (xcd + 8 * (idx / ngrp)) * ngrp + idx % ngrp; }
+    const int kt = bid % n_kt; bid /= n_kt;
+    const int nt = bid % n_nt; bid /= n_nt;
+    const int par = bid % a.npar; const int split = bid / a.npar;
+    const int k0 = kt * 64, n0 = nt * 64, py = par >> 1, px = par & 1, par_off = par * 4;
+    const int tiles = a.B * a.n_ty * a.n_tx;
+    const int ntile = split < tiles ? (tiles - split + a.nsplit - 1) / a.nsplit : 0;
+
+    if (wave >= 4) {
+        // ---- producers ----------------------------------------------------------------------------------------------------
+        const int ptid = tid - 256, ck = ptid & 7, cbase = k0 + ck * 8, nbase = n0 + ck * 8;
+        const bool cvalid = cbase < a.Cin;
+        // two register sets: the loads of tile j+3 are issued while tile j+1 is written to LDS, so every load has two tile periods to
+        // land (with one set the loop ran at one tile per memory latency: ~45 KB in flight per CU / ~4 us = 2.9 TB/s chip-wide)
+        struct PSet { u32x4 ra[NA], rd[4]; unsigned okm; GnCoef<T> gk; };
+        PSet s0, s1;
+        auto issue = [&](PSet& ps, int j) __attribute__((always_inline)) {
+            const int tile = split + j * a.nsplit;
+            const int tx = tile % a.n_tx, ty = (tile / a.n_tx) % a.n_ty, b = tile / (a.n_tx * a.n_ty);
+            const int my0 = ty * 4, mx0 = tx * 32, iy0 = my0 - 1, ix0 = mx0 - 1;
+            ps.gk.load(a.gn_ab + (size_t)b * a.Cin + (cvalid ? cbase : 0), a.gn_ab != nullptr && cvalid);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (ptid >> 3) + 32 * i, my = my0 + (m >> 5), mx = mx0 + (m & 31);
+                ps.rd[i] = u32x4{0u, 0u, 0u, 0u};
+                if (nbase < a.Cout && my < a.MH && mx < a.MW)
+                    ps.rd[i] = *(const u32x4*)((const T*)a.dy + ((size_t)(b * a.Hout + my * a.OS + py) * a.Wout + mx * a.OS + px) * a.Cout + nbase);
+            }
+            ps.okm = 0;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int pxl = (ptid >> 3) + 32 * u;
+                const int hy = pxl / PITCH, hx = pxl - hy * PITCH, iy = iy0 + hy, ix = ix0 + hx;
+                ps.ra[u] = u32x4{0u, 0u, 0u, 0u};
+                if (pxl < NPA && cvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                    ps.okm |= 1u << u;
+                    ps.ra[u] = *(const u32x4*)((const T*)a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.Cin + cbase);
+                }
+            }
+        };
+        auto commit = [&](PSet& ps, int buf) __attribute__((always_inline)) {
+            unsigned char* const As = smem + buf * BUF;
+            unsigned char* const dstA = As + ((ck >> 2) * NPA * 32 + (ck & 3) * 8) * 2;
+            unsigned char* const dstD = As + A_BYTES + ((ck >> 2) * 128 * 32 + (ck & 3) * 8) * 2;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int pxl = (ptid >> 3) + 32 * u;
+                if (pxl < NPA) {
+                    u32x4 v = ps.ra[u];
+                    if (((ps.okm >> u) & 1u) && a.gn_ab) v = ps.gk.template apply<SILU>(v);
+                    *(u32x4*)(dstA + pxl * 64) = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(dstD + ((ptid >> 3) + 32 * i) * 64) = ps.rd[i];
+        };
+        // tile j lives in set j & 1 and goes to LDS buffer j & 1
+        if (ntile > 0) issue(s0, 0);
+        if (ntile > 1) issue(s1, 1);
+        if (ntile > 0) { commit(s0, 0); if (ntile > 2) issue(s0, 2); }
+        __syncthreads();
+        const bool idle = (a.dbg & 1) != 0;
+        for (int j = 0; j < ntile; j += 2) {
+            if (j + 1 < ntile && !idle) { commit(s1, 1); if (j + 3 < ntile) issue(s1, j + 3); }
+            __syncthreads();
+            if (j + 1 >= ntile) break;
+            if (j + 2 < ntile && !idle) { commit(s0, 0); if (j + 4 < ntile) issue(s0, j + 4); }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- consumers ------------------------------------------------------------------------------------------------------------
+    const int r = lane & 31, h = lane >> 5, wn = wave >> 1, wk = wave & 1;
+    int toff[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) toff[t] = ((a.tapinfo_dy(par_off + t) + 1) * PITCH + a.tapinfo_dx(par_off + t) + 1) * 64;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    const int g = lane >> 4, pix_l = 8 * (g >> 1) + ((lane & 15) >> 2), c_l = 16 * (g & 1) + 4 * (lane & 3);
+    const int d_off = A_BYTES + ((wn * 128 + pix_l) * 32 + c_l) * 2, a_off = ((wk * NPA + pix_l) * 32 + c_l) * 2;
+    __syncthreads();
+    // The 8 k-steps x NTAPS MFMAs of a tile are one straight-line software pipeline: the transposed reads of step s + PF are issued
+    // before the MFMA of step s (a ring of RING fragment pairs), so an MFMA never waits for the LDS latency of its own operands
+    // (issuing read, wait, MFMA per step ran at 1/4 of the MFMA rate).
+    constexpr int NSTEP = 8 * NTAPS, RING = 8, PF = 6;
+    for (int j = 0; j < ntile; ++j) {
+        if (a.dbg & 2) { __syncthreads(); continue; }
+        const unsigned char* const base = smem + (j & 1) * BUF;
+        const unsigned char* const Dp = base + d_off;
+        const unsigned char* apt[NTAPS];
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) apt[t] = base + a_off + toff[t];
+        s16x4 dq[2][2], aq[RING][2];
+        dq[0][0] = lds_tr16(Dp); dq[0][1] = lds_tr16(Dp + 256);
+#pragma unroll
+        for (int s0 = 0; s0 < PF; ++s0) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ks = s0 / NTAPS, t = s0 % NTAPS;
+            const int koff = ((ks >> 1) * PITCH + 16 * (ks & 1)) * 64;
+            aq[s0 % RING][0] = lds_tr16(apt[t] + koff); aq[s0 % RING][1] = lds_tr16(apt[t] + koff + 256);
+        }
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            const int ks = st / NTAPS, t = st % NTAPS;
+            if (t == 0 && ks + 1 < 8) { dq[(ks + 1) & 1][0] = lds_tr16(Dp + (ks + 1) * 1024); dq[(ks + 1) & 1][1] = lds_tr16(Dp + (ks + 1) * 1024 + 256); }
+            const int nx = st + PF;
+            if (nx < NSTEP) {
+                const int ks2 = nx / NTAPS, t2 = nx % NTAPS;
+                const int koff = ((ks2 >> 1) * PITCH + 16 * (ks2 & 1)) * 64;
+                aq[nx % RING][0] = lds_tr16(apt[t2] + koff); aq[nx % RING][1] = lds_tr16(apt[t2] + koff + 256);
+            }
+            const s16x4 d0 = dq[ks & 1][0], d1 = dq[ks & 1][1], a0 = aq[st % RING][0], a1 = aq[st % RING][1];
+            const s16x8 dv = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dv), __builtin_bit_cast(bf16x8, av), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the issue order: the scheduler otherwise sinks the reads next to their use
+        }
+        __syncthreads();
+    }
+    if (a.dbg & 4) return;
+    const int k = k0 + wk * 32 + r;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int wt = a.tapinfo_w(par_off + t);
+        float* const o = a.part + ((size_t)split * a.taps_w + wt) * a.Cout * a.Cin;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n0 + wn * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (n < a.Cout && k < a.Cin) o[(size_t)n * a.Cin + k] = acc[t][q];
+        }
+    }
+}
+static constexpr size_t wgrad_bf16_ws_lds() { return (size_t)2 * (2 * WgGeom<1>::ROWS * WgGeom<1>::PITCH + 2 * 128) * 64; }
+
 template <int IS> static constexpr size_t wgrad_bf16_lds() { return (size_t)(2 * WgGeom<IS>::ROWS * WgGeom<IS>::PITCH + 2 * 128) * 64; }
 
 template <int IS, int WN, int WK> static constexpr size_t wgrad_lds() { return (size_t)(WgGeom<IS>::ROWS * WgGeom<IS>::PITCH * 32 * WK + 128 * 32 * WN) * 4; }
@@ -815,6 +969,12 @@ static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt,
 {
     if (dtype == 1) {
         *nt = 64; *kt = 64;
+        static const bool no_ws = getenv("CCN_WGRAD_NO_WS") != nullptr;         // A/B switch: single-role kernel everywhere
+        if (!no_ws) {
+            if (!silu && kind == KIND_C3S1) { *lds = wgrad_bf16_ws_lds(); return (wgrad_fn_t)wgrad_bf16_ws_kernel<9, false>; }
+            if (kind == KIND_C3S1) { *lds = wgrad_bf16_ws_lds(); return (wgrad_fn_t)wgrad_bf16_ws_kernel<9, true>; }
+            if (kind == KIND_CT4) { *lds = wgrad_bf16_ws_lds(); return (wgrad_fn_t)wgrad_bf16_ws_kernel<4, true>; }
+        }
         if (!silu && kind == KIND_C3S1) { *lds = wgrad_bf16_lds<1>(); return (wgrad_fn_t)wgrad_bf16_kernel<1, 9, false>; }
         switch (kind) {
             case KIND_C3S2: *lds = wgrad_bf16_lds<2>(); return (wgrad_fn_t)wgrad_bf16_kernel<2, 9>;
@@ -853,8 +1013,11 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
     const int tiles = B * ((MH + 3) / 4) * ((MW + 31) / 32);
     const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
     static const int target_bf16 = getenv("CCN_WGRAD_WGS") ? atoi(getenv("CCN_WGRAD_WGS")) : 512;
-    int ns = ((dtype == 1 ? target_bf16 : 768) + groups - 1) / groups;     // 2-3 workgroups per CU
+    const bool ws = dtype == 1 && lds == wgrad_bf16_ws_lds();
+    static const int target_ws = getenv("CCN_WGRAD_WS_WGS") ? atoi(getenv("CCN_WGRAD_WS_WGS")) : 256;
+    int ns = ((ws ? target_ws : (dtype == 1 ? target_bf16 : 768)) + groups - 1) / groups;     // 1 (warp-specialised) or 2-3 workgroups per CU
     if (ns > tiles) ns = tiles;
+    if (ns >= 8) ns &= ~7;                                        // whole XCD rounds (see the kernels' block mapping)
     return ns < 1 ? 1 : ns;
 }
 hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
@@ -865,7 +1028,10 @@ hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
     const int epc = dtype == 0 ? 4 : 8;
     if (a.Cin % epc || a.Cout % epc) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(((a.Cin + kt - 1) / kt) * ((a.Cout + nt - 1) / nt) * a.npar * a.nsplit);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
+    const bool ws = dtype == 1 && lds == wgrad_bf16_ws_lds();
+    static const int dbg = getenv("CCN_WG_DBG") ? atoi(getenv("CCN_WG_DBG")) : 0;
+    WgArgs d = a; d.dbg = dbg;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(ws ? 512 : 256), lds, s, d);
     return hipGetLastError();
 }
 
