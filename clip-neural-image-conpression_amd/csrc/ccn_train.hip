@@ -81,6 +81,8 @@ struct ccn_trainer_s {
     std::vector<Layer> layers;
     int F = 0;
     float* zero_bias = nullptr;
+    hipStream_t side = nullptr;           // weight gradients run here, beside the data-gradient chain (nothing downstream reads them)
+    std::vector<hipEvent_t> sync_pool; size_t sync_used = 0;
     PackDesc* pack_descs = nullptr; int n_pack = 0;
     LinDesc* lin_descs = nullptr; int n_lin = 0, max_lin_n = 0;
     std::vector<void*> allocs;
@@ -257,6 +259,27 @@ struct Walk {
         hipEvent_t e = tr->ev_pool[tr->ev_used++];
         if (hipEventRecord(e, st) != hipSuccess) return;
         tr->marks.push_back({fam, e, flops});
+    }
+    // fork: the side stream continues from this point of the main stream; join: the main stream waits for everything on the side
+    hipStream_t wg_stream = nullptr;
+    bool fork_side()
+    {
+        static const bool off_ = getenv("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
+        wg_stream = st;
+        if (off_ || tr->profiling || !tr->side) return true;
+        if (tr->sync_used == tr->sync_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return true; tr->sync_pool.push_back(e); }
+        hipEvent_t e = tr->sync_pool[tr->sync_used++];
+        if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) { err = "stream fork failed"; return false; }
+        wg_stream = tr->side;
+        return true;
+    }
+    bool join_side()
+    {
+        if (!tr->side || tr->sync_used == 0) return true;
+        if (tr->sync_used == tr->sync_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = "event create failed"; return false; } tr->sync_pool.push_back(e); }
+        hipEvent_t e = tr->sync_pool[tr->sync_used++];
+        if (hipEventRecord(e, tr->side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) { err = "stream join failed"; return false; }
+        return true;
     }
     void* take(size_t bytes) { off = align_up(off, 256); void* p = base ? base + off : nullptr; off += bytes; return p; }
     TT new_tensor(int C, int h, int w) { TT t; t.C = C; t.H = h; t.W = w; t.p = take((size_t)B * h * w * C * tr->elem); return t; }
@@ -471,10 +494,11 @@ struct Walk {
         fill_taps(a.tapinfo, kind, false);
         want(need.scr_wg, (size_t)a.nsplit * a.taps_w * Cout * Cin * 4);
         if (!launch) return true;
+        if (!fork_side()) return false;
         mark(TF_WGRAD, 2.0 * B * g.Hout * g.Wout * (double)Cov * (kind == KIND_CT4 ? 4 : (kind == KIND_STEM ? 1 : 9)) * Civ);
-        if (!ok(launch_wgrad(tr->cfg.dtype, kind, a, st), "wgrad")) return false;
+        if (!ok(launch_wgrad(tr->cfg.dtype, kind, a, wg_stream), "wgrad")) return false;
         mark(TF_WGRAD_REDUCE);
-        return ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, Cout, Cin, Cov, Civ, kind == KIND_CT4 ? 1 : 0, gdst, st), "wgrad_reduce");
+        return ok(launch_wgrad_reduce(scr_wg, a.nsplit, a.taps_w, Cout, Cin, Cov, Civ, kind == KIND_CT4 ? 1 : 0, gdst, wg_stream), "wgrad_reduce");
     }
     // GroupNorm(+SiLU) backward of the norm reading tensor `x`: dA -> out (may alias dA)
     bool gn_bwd(const TT& x, const TNorm& n, const float2* ab, const float2* stats, const void* dA, void* out, bool silu, const void* addend,
@@ -652,6 +676,7 @@ int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
     good = good && alloc_dev(tr, (size_t)(maxc + 256) * 4, &zb, err);
     if (good && hipMemset(zb, 0, (size_t)(maxc + 256) * 4) != hipSuccess) { good = false; err = "hipMemset failed"; }
     if (good && (conv_prepare() != hipSuccess || wgrad_prepare() != hipSuccess)) { good = false; err = "kernel attribute setup failed"; }
+    if (good && hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) { tr->side = nullptr; }
     if (good) {
         // descriptor tables of the grouped launches (offsets into the caller's flat buffers are fixed by the architecture)
         std::vector<PackDesc> pd;
@@ -701,6 +726,8 @@ int ccn_train_destroy(ccn_trainer_t tr)
     if (!tr) return CCN_OK;
     for (void* p : tr->allocs) (void)hipFree(p);
     for (hipEvent_t e : tr->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : tr->sync_pool) (void)hipEventDestroy(e);
+    if (tr->side) (void)hipStreamDestroy(tr->side);
     delete tr;
     return CCN_OK;
 }
@@ -765,7 +792,9 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
     w.place_scratch(si);
     if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) return tfail(CCN_EHIP, w.err);
     w.launch = true;
+    tr->sync_used = 0;
     if (!w.backward(x_t_dev, z_dev, d_eps_dev)) return tfail(CCN_EHIP, w.err);
+    if (!w.join_side()) return tfail(CCN_EHIP, w.err);
     w.mark(-1);
     return CCN_OK;
 }

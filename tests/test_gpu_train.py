@@ -164,3 +164,60 @@ def test_backward_requires_matching_forward():
         tr.backward(flat, torch.zeros_like(flat), x, z, torch.zeros_like(x))
     with pytest.raises(ValueError):
         tr.forward(flat, torch.zeros((1, 3, 30, 32), device=DEV), z, torch.zeros(1, dtype=torch.int64, device=DEV))
+
+
+def test_bf16_gradients_at_c2_widths_against_fp32_mode():
+    """BASELINE configs[4]'s architecture (base 128, (1,2,2)) at 128 px, batch 2: every kernel choice of the bf16 step (transposed-read
+    weight gradients on the warp-specialised kernel, 8-row forward / data-gradient tiles, pre-activated tensors) against the fp32 mode
+    of the same library, whose gradients the other tests pin to the oracle."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
+    B, S = 2, 128
+    g = torch.Generator("cpu").manual_seed(21)
+    x_t = torch.randn((B, 3, S, S), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.tensor([450, 980]); target = torch.randn((B, 3, S, S), generator=g)
+    l32, g32, _ = grads_via_autograd(make_net(sd, 128, (1, 2, 2)), x_t, z, t, target)
+    l16, g16, _ = grads_via_autograd(make_net(sd, 128, (1, 2, 2), dtype="bf16"), x_t, z, t, target)
+    assert abs(float(l16) - float(l32)) < 2e-2 * float(l32)
+    worst = ("", 1.0)
+    for k, r in g32.items():
+        a = g16[k].double().flatten(); b = r.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        if cos < worst[1]:
+            worst = (k, cos)
+        assert cos > 0.97, (k, cos)
+        assert 0.9 < float(a.norm() / (b.norm() + 1e-30)) < 1.1, k
+    print(f"bf16 vs fp32 mode at base 128: worst cosine {worst[1]:.4f} ({worst[0]})")
+
+
+def test_backward_accumulates_into_the_gradient_buffer():
+    """ccn_train_backward adds to grads_dev (torch's .grad accumulation): two backward passes give twice the gradient."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    st = net.train_state()
+    x0, z, t, noise = (torch.from_numpy(GOLD[k]).to(DEV) for k in ("x_t", "z", "t", "noise"))
+    eps = st.trainer.forward(st.fp.flat, x0, z, t)
+    _, d = _native.mse_loss_grad(eps, noise)
+    g1 = torch.zeros_like(st.fp.flat); g2 = torch.zeros_like(st.fp.flat)
+    st.trainer.backward(st.fp.flat, g1, x0, z, d)
+    st.trainer.backward(st.fp.flat, g2, x0, z, d)
+    st.trainer.backward(st.fp.flat, g2, x0, z, d)
+    assert float(g1.abs().max()) > 0
+    assert float((g2 - 2 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+
+
+def test_mse_loss_grad_and_adamw_kernels_against_torch():
+    g = torch.Generator("cpu").manual_seed(5)
+    eps = torch.randn((3, 3, 40, 24), generator=g); tgt = torch.randn((3, 3, 40, 24), generator=g)
+    loss, d = _native.mse_loss_grad(eps.to(DEV), tgt.to(DEV))
+    e = eps.clone().requires_grad_(True)
+    ref = F.mse_loss(e, tgt); ref.backward()
+    assert abs(float(loss) - float(ref.detach())) < 1e-6 and float((d.cpu() - e.grad).abs().max()) < 1e-9
+    n = 10007
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 0.01
+    pt = torch.nn.Parameter(p.clone()); opt = torch.optim.AdamW([pt], lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    pd = p.to(DEV).clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        pt.grad = gr * step
+        opt.step()
+        _native.adamw_step(pd, (gr * step).to(DEV), m, v, 3e-4, 0.9, 0.99, 1e-8, 0.05, step)
+    assert float((pd.cpu() - pt.detach()).abs().max()) < 2e-6
