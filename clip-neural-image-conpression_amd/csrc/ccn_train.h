@@ -16,6 +16,8 @@ enum PackMode {
     PK_DGT = 4,       // ConvTranspose2d 4x4 s2        -> data-gradient operand for the stride-2 kernel run with 16 taps
     PK_STEM = 5,      // Conv2d (O, img_ch, 3, 3)      -> im2col operand, 1 "tap", K = img_ch * 9
     PK_HEAD_DG = 6,   // Conv2d (img_ch, C, 3, 3)      -> data gradient through the im2col kernel: N = C, K = img_ch * 9, taps flipped
+    PK_FRAG3 = 7,     // Conv2d 3x3 s1, bf16           -> MFMA fragment order of the persistent kernel (ccn_conv_pr.hip), forward operand
+    PK_FRAG3_DG = 8,  // Conv2d 3x3 s1, bf16           -> the same order for the data-gradient operand (taps flipped, N = I, K = O)
 };
 hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s);
 

@@ -47,6 +47,8 @@ struct TConvW {
     int BN = 0, Cin_pad = 0, Cout_pad = 0;      // forward operand
     int dkind = KIND_C3S1, dBN = 0, dCin_pad = 0, dCout_pad = 0, dtaps = 9;   // data-gradient operand (roles of Cin / Cout swapped)
     void* wf = nullptr; void* wd = nullptr;
+    void* wf_frag = nullptr; void* wd_frag = nullptr;   // 3x3 s1, bf16: fragment-ordered operands for the persistent kernel, else null
+    PackDesc pd_f{}, pd_d{}, pf_f{}, pf_d{};             // repack descriptors: plain / fragment, forward / data gradient
 };
 struct TNorm { int C = 0, pg = -1, pb = -1; };
 struct TLin { int pw = -1, pb = -1, N = 0, K = 0; };
@@ -64,7 +66,7 @@ const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd",
                                         "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
 struct Mark { int fam; hipEvent_t ev; double flops; };
 
-struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; };
+struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; PackDesc* packs = nullptr; int n_packs = 0; };
 
 }  // namespace
 
@@ -83,7 +85,6 @@ struct ccn_trainer_s {
     float* zero_bias = nullptr;
     hipStream_t side = nullptr;           // weight gradients run here, beside the data-gradient chain (nothing downstream reads them)
     std::vector<hipEvent_t> sync_pool; size_t sync_used = 0;
-    PackDesc* pack_descs = nullptr; int n_pack = 0;
     LinDesc* lin_descs = nullptr; int n_lin = 0, max_lin_n = 0;
     std::vector<void*> allocs;
     std::map<std::string, ShapeInfo> shapes;
@@ -177,6 +178,12 @@ bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
     w.Cin_pad = fkind == KIND_STEM ? cke : (int)align_up(w.Cin, cke);
     const int ftaps = fkind == KIND_CT4 ? 16 : (fkind == KIND_STEM ? 1 : 9);
     if (!alloc_dev(tr, (size_t)ftaps * w.Cout_pad * w.Cin_pad * tr->elem, &w.wf, err)) return false;
+    const long long src = (long long)tr->params[w.pw].off;
+    switch (fkind) {
+        case KIND_CT4: w.pd_f = {src, w.wf, PK_CONVT, w.Cout, w.Cin, 16, w.Cout_pad, w.Cin_pad}; break;
+        case KIND_STEM: w.pd_f = {src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad}; break;
+        default: w.pd_f = {src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad}; break;
+    }
     if (fkind == KIND_STEM) return true;                     // the image needs no gradient
     // data gradient: a convolution from Cout back to Cin
     switch (fkind) {
@@ -188,7 +195,24 @@ bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
     w.dBN = conv_bn_for(w.Cin, w.dkind);
     w.dCout_pad = (int)align_up(w.Cin, w.dBN);
     w.dCin_pad = w.dkind == KIND_STEM ? cke : (int)align_up(w.Cout, cke);
-    return alloc_dev(tr, (size_t)w.dtaps * w.dCout_pad * w.dCin_pad * tr->elem, &w.wd, err);
+    if (!alloc_dev(tr, (size_t)w.dtaps * w.dCout_pad * w.dCin_pad * tr->elem, &w.wd, err)) return false;
+    switch (fkind) {
+        case KIND_C3S1: w.pd_d = {src, w.wd, PK_DG3S1, w.Cout, w.Cin, 9, w.dCout_pad, w.dCin_pad}; break;
+        case KIND_C3S2: w.pd_d = {src, w.wd, PK_DG3S2, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad}; break;
+        case KIND_CT4: w.pd_d = {src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad}; break;
+        case KIND_HEAD: w.pd_d = {src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad}; break;
+    }
+    if (fkind == KIND_C3S1 && tr->elem == 2) {
+        if (w.BN == 128 && w.Cin_pad >= 128) {
+            if (!alloc_dev(tr, (size_t)9 * w.Cout_pad * w.Cin_pad * 2, &w.wf_frag, err)) return false;
+            w.pf_f = {src, w.wf_frag, PK_FRAG3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad};
+        }
+        if (w.dBN == 128 && w.dCin_pad >= 128) {
+            if (!alloc_dev(tr, (size_t)9 * w.dCout_pad * w.dCin_pad * 2, &w.wd_frag, err)) return false;
+            w.pf_d = {src, w.wd_frag, PK_FRAG3_DG, w.Cout, w.Cin, 9, w.dCout_pad, w.dCin_pad};
+        }
+    }
+    return true;
 }
 
 void fill_taps(int* tapinfo, int kind, bool four_by_four)
@@ -246,6 +270,7 @@ struct Walk {
     std::vector<ResSave> rs;
     TT stem_out; std::vector<TT> down_in, down_out, up_in, up_out;
     TT head_in; float2 *ab_o = nullptr, *st_o = nullptr;
+    std::vector<PackDesc> pack_list;      // repacks this shape needs, collected by the measuring walk (one per conv launch)
     int g_sum_rows = 0;                   // > 0: scr_film holds per-block channel sums of the current gradient tensor (rows = B * blocks)
 
     Walk(ccn_trainer_s* t, int B_, int H_, int W_, void* ws, bool l, hipStream_t s, const float* p, float* g)
@@ -262,6 +287,7 @@ struct Walk {
     }
     // fork: the side stream continues from this point of the main stream; join: the main stream waits for everything on the side
     hipStream_t wg_stream = nullptr;
+    const PackDesc* shape_packs = nullptr; int n_shape_packs = 0;
     bool fork_side()
     {
         static const bool off_ = getenv("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
@@ -295,38 +321,21 @@ struct Walk {
     }
 
     // ---- forward pieces --------------------------------------------------------------------------------------------------
-    bool pack(const TConvW& w)
-    {
-        if (!launch) return true;
-        mark(TF_PACK);
-        const int dt = tr->cfg.dtype;
-        const float* src = par(w.pw);
-        switch (w.kind) {
-            case KIND_C3S1: case KIND_C3S2:
-                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
-                return ok(launch_pack_w(dt, src, w.wd, w.kind == KIND_C3S1 ? PK_DG3S1 : PK_DG3S2, w.Cout, w.Cin, w.dtaps, w.dCout_pad, w.dCin_pad, st), "pack");
-            case KIND_CT4:
-                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONVT, w.Cout, w.Cin, 16, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
-                return ok(launch_pack_w(dt, src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad, st), "pack");
-            case KIND_STEM:
-                return ok(launch_pack_w(dt, src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad, st), "pack");
-            case KIND_HEAD:
-                if (!ok(launch_pack_w(dt, src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad, st), "pack")) return false;
-                return ok(launch_pack_w(dt, src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad, st), "pack");
-        }
-        return true;
-    }
-
     // generic launch of the forward conv kernels.  `kind`: kernel family; N = output channels of this launch, K = input channels
-    bool run_conv(int fam, int kind, bool four, const void* wop, int BN, int K, int Kpad, int N, int Npad, const float* bias, const void* in, int Hin, int Win,
-                  TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out)
+    bool run_conv(int fam, int kind, bool four, const PackDesc& plain, const PackDesc& frag, int BN, int K, int Kpad, int N, int Npad, const float* bias,
+                  const void* in, int Hin, int Win, TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out)
     {
         const Geom g = geom_of(kind, Hin, Win, four);
         const int cke = tr->elem == 2 ? 64 : 32;
         const int n_nt = Npad / BN;
         const int th = conv_tile_rows(kind, BN, B, g.MH, g.MW, g.npar, n_nt);
+        // the persistent register-weight kernel (ccn_conv_pr.hip) where the inference plan would use it: 3x3 s1, bf16, 8-row tiles
+        static const bool no_pr = getenv("CCN_TRAIN_NO_PR") != nullptr;     // A/B switch
+        const bool pr = !no_pr && kind == KIND_C3S1 && frag.dst && conv_pr_selected(tr->cfg.dtype, kind, BN, th) && Kpad / cke >= 2 && !(res && film) &&
+                        (double)B * g.Hout * g.Wout * N * tr->elem < 2.0e9;
+        if (!base) pack_list.push_back(pr ? frag : plain);      // measuring walk: this shape's repack list
         ConvArgs a{};
-        a.in = in; a.w = wop; a.wfrag = nullptr; a.bias = bias; a.out = out_p;
+        a.in = in; a.w = plain.dst; a.wfrag = pr ? frag.dst : nullptr; a.use_pr = pr ? 1 : 0; a.bias = bias; a.out = out_p;
         a.gn_ab = gn_ab; a.film = film; a.res = res;
         a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = K; a.Cin_pad = Kpad;
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = N; a.Cout_pad = Npad;
@@ -335,15 +344,15 @@ struct Walk {
         a.nchunk = Kpad / cke;
         a.silu = 1; a.ksplit = 1;
         a.G = groups_for(N); a.cpg = N / a.G;
-        a.nslot = a.n_ty * a.n_tx * g.npar * n_nt;
+        a.nslot = a.n_ty * a.n_tx * g.npar * n_nt * (pr ? 4 : 1);          // the persistent kernel publishes one partial per producer wave
         a.film_bstride = tr->F;
         a.bn = BN;
-        a.fin_blocks = a.nslot;
+        a.fin_blocks = a.n_ty * a.n_tx * g.npar * n_nt;
         a.eps_out = eps_out;
         fill_taps(a.tapinfo, kind, four);
         if (want_part && out) {
             out->part = (float2*)take((size_t)B * a.G * a.nslot * sizeof(float2));
-            out->n_sp = a.n_ty * a.n_tx * g.npar; out->n_nt = n_nt; out->bn = BN;
+            out->n_sp = a.n_ty * a.n_tx * g.npar * (pr ? 4 : 1); out->n_nt = n_nt; out->bn = BN;
             a.part = out->part;
         }
         if (!launch) return true;
@@ -353,14 +362,14 @@ struct Walk {
     bool conv_fwd(const TConvW& w, const TT& in, TT& out, const float2* gn_ab, const float* film, const TT* res, bool want_part, const void* in_override = nullptr,
                   float* eps_out = nullptr)
     {
-        return run_conv(TF_CONV_FWD, w.kind, false, w.wf, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
+        return run_conv(TF_CONV_FWD, w.kind, false, w.pd_f, w.pf_f, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
                         &out, out.p, gn_ab, film, res ? res->p : nullptr, want_part, eps_out);
     }
     // dX = conv'(dY): N = the forward conv's Cin
     bool conv_dgrad(const TConvW& w, const void* dy, int Hdy, int Wdy, void* dx, const void* res)
     {
         g_sum_rows = 0;                                         // the gradient tensor that follows comes out of a conv: no channel sums
-        return run_conv(TF_CONV_DGRAD, w.dkind, w.kind == KIND_CT4, w.wd, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
+        return run_conv(TF_CONV_DGRAD, w.dkind, w.kind == KIND_CT4, w.pd_d, w.pf_d, w.dBN, w.kind == KIND_HEAD ? tr->cfg.img_ch : w.Cout, w.dCin_pad, w.Cin, w.dCout_pad, tr->zero_bias, dy, Hdy, Wdy,
                         nullptr, dx, nullptr, nullptr, res, false, nullptr);
     }
     bool preact(const TT& t, const float2* ab, const TT& out)
@@ -400,7 +409,7 @@ struct Walk {
     {
         if (launch) {
             mark(TF_PACK);
-            if (!ok(launch_pack_group(tr->cfg.dtype, P, tr->pack_descs, tr->n_pack, st), "pack")) return false;
+            if (!ok(launch_pack_group(tr->cfg.dtype, P, shape_packs, n_shape_packs, st), "pack")) return false;
         }
         if (!conditioning(z, t)) return false;
         TT x; std::vector<TT> skips;
@@ -456,7 +465,7 @@ struct Walk {
                     head_in = x;
                     if (!gn_fwd(x, tr->out_norm, ab_o, st_o)) return false;
                     TT none;
-                    if (!run_conv(TF_CONV_FWD, KIND_HEAD, false, tr->head.wf, tr->head.BN, tr->head.Cin, tr->head.Cin_pad, tr->head.Cout, tr->head.Cout_pad,
+                    if (!run_conv(TF_CONV_FWD, KIND_HEAD, false, tr->head.pd_f, tr->head.pf_f, tr->head.BN, tr->head.Cin, tr->head.Cin_pad, tr->head.Cout, tr->head.Cout_pad,
                                   launch ? par(tr->head.pb) : nullptr, x.p, x.H, x.W, &none, nullptr, ab_o, nullptr, nullptr, false, eps)) return false;
                     break;
                 }
@@ -641,6 +650,13 @@ int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
     si.tensors = align_up(w.off, 256);
     si.total = si.tensors + align_up(si.scr_wg, 256) + align_up(si.scr_gn, 256) + align_up(si.scr_film, 256) + align_up(si.scr_col, 256) +
                5 * 256;
+    {
+        std::string err;
+        void* dev = nullptr;
+        if (!alloc_dev(tr, w.pack_list.size() * sizeof(PackDesc), &dev, err)) return tfail(CCN_EHIP, err);
+        if (hipMemcpy(dev, w.pack_list.data(), w.pack_list.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess) return tfail(CCN_EHIP, "descriptor upload failed");
+        si.packs = (PackDesc*)dev; si.n_packs = (int)w.pack_list.size();
+    }
     tr->shapes[key] = si;
     *out = si;
     return CCN_OK;
@@ -679,40 +695,15 @@ int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
     if (good && hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) { tr->side = nullptr; }
     if (good) {
         // descriptor tables of the grouped launches (offsets into the caller's flat buffers are fixed by the architecture)
-        std::vector<PackDesc> pd;
-        auto add_pack = [&](const TConvW& w) {
-            const long long src = (long long)tr->params[w.pw].off;
-            switch (w.kind) {
-                case KIND_C3S1: case KIND_C3S2:
-                    pd.push_back({src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad});
-                    pd.push_back({src, w.wd, w.kind == KIND_C3S1 ? PK_DG3S1 : PK_DG3S2, w.Cout, w.Cin, w.dtaps, w.dCout_pad, w.dCin_pad});
-                    break;
-                case KIND_CT4:
-                    pd.push_back({src, w.wf, PK_CONVT, w.Cout, w.Cin, 16, w.Cout_pad, w.Cin_pad});
-                    pd.push_back({src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad});
-                    break;
-                case KIND_STEM: pd.push_back({src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad}); break;
-                case KIND_HEAD:
-                    pd.push_back({src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad});
-                    pd.push_back({src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad});
-                    break;
-            }
-        };
-        add_pack(tr->stem); add_pack(tr->head);
-        for (const TRes& r : tr->res) { add_pack(r.c1); add_pack(r.c2); }
-        for (const TConvW& w : tr->downs) add_pack(w);
-        for (const TConvW& w : tr->ups) add_pack(w);
         std::vector<LinDesc> ld;
         for (const TRes& r : tr->res) {
             ld.push_back({(long long)tr->params[r.fs.pw].off, (long long)tr->params[r.fs.pb].off, r.C, r.film_off});
             ld.push_back({(long long)tr->params[r.fh.pw].off, (long long)tr->params[r.fh.pb].off, r.C, r.film_off + r.C});
             if (r.C > tr->max_lin_n) tr->max_lin_n = r.C;
         }
-        void *pdd = nullptr, *ldd = nullptr;
-        good = alloc_dev(tr, pd.size() * sizeof(PackDesc), &pdd, err) && alloc_dev(tr, ld.size() * sizeof(LinDesc), &ldd, err);
-        if (good && (hipMemcpy(pdd, pd.data(), pd.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess ||
-                     hipMemcpy(ldd, ld.data(), ld.size() * sizeof(LinDesc), hipMemcpyHostToDevice) != hipSuccess)) { good = false; err = "descriptor upload failed"; }
-        tr->pack_descs = (PackDesc*)pdd; tr->n_pack = (int)pd.size();
+        void* ldd = nullptr;
+        good = alloc_dev(tr, ld.size() * sizeof(LinDesc), &ldd, err);
+        if (good && hipMemcpy(ldd, ld.data(), ld.size() * sizeof(LinDesc), hipMemcpyHostToDevice) != hipSuccess) { good = false; err = "descriptor upload failed"; }
         tr->lin_descs = (LinDesc*)ldd; tr->n_lin = (int)ld.size();
     }
     if (!good) { ccn_train_destroy(tr); return tfail(CCN_EHIP, err); }
@@ -772,6 +763,7 @@ int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_
     if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(si.total));
     Walk w(tr, B, H, W, workspace_dev, true, (hipStream_t)stream, params_dev, nullptr);
     w.place_scratch(si);
+    w.shape_packs = si.packs; w.n_shape_packs = si.n_packs;
     if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) return tfail(CCN_EHIP, w.err);
     w.mark(-1);
     tr->fB = B; tr->fH = H; tr->fW = W; tr->fws = workspace_dev; tr->fx = x_t_dev;

@@ -130,6 +130,27 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
 #pragma unroll
                     for (int t = 0; t < 16; ++t) v[t] = p[t]; }
                 break;
+            case PK_FRAG3:
+                if (n < O && k < I) { const float* p = w + ((size_t)n * I + k) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = p[t]; }
+                break;
+            case PK_FRAG3_DG:
+                if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = p[8 - t]; }
+                break;
+        }
+        if (d.mode == PK_FRAG3 || d.mode == PK_FRAG3_DG) {
+            // [Cin chunk of 64][N/32][step j = dx*12 + kk*3 + dy][lane = h*32 + r][8]: lane (r, h) of column block nn holds output channel
+            // nn*32 + r and input channels chunk*64 + (2 kk + h)*8 + e (pack_conv3 in ccn_api.hip)
+            const int c = k >> 6, kk2 = (k & 63) >> 3, e = k & 7, nn = n >> 5, lane = (kk2 & 1) * 32 + (n & 31), n32 = Np >> 5;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int j = (t % 3) * 12 + (kk2 >> 1) * 3 + t / 3;
+                dst[((((size_t)c * n32 + nn) * 36 + j) * 64 + lane) * 8 + e] = to_elem<T>(v[t]);
+            }
+            continue;
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t)
