@@ -59,7 +59,7 @@ SIGNATURES = {
     "ccn_train_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_train_profile_enable": (c_i32, [c_vp, c_i32]),
     "ccn_train_profile_read": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f32), ctypes.POINTER(c_i32),
-                                       ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
     "ccn_mse_loss_grad": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "ccn_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "ccn_last_error": (ctypes.c_char_p, []),
@@ -339,10 +339,11 @@ class NativeTrainer:
 
     def profile_read(self) -> List[dict]:
         cap = 16
-        names = (ctypes.c_char_p * cap)(); ms = (c_f32 * cap)(); calls = (c_i32 * cap)(); fl = (ctypes.c_double * cap)(); n = c_i32()
+        names = (ctypes.c_char_p * cap)(); ms = (c_f32 * cap)(); calls = (c_i32 * cap)(); n = c_i32()
+        fl = (ctypes.c_double * cap)(); by = (ctypes.c_double * cap)()
         with torch.cuda.device(self.device):
-            check(self.lib.ccn_train_profile_read(self.h, names, ms, calls, fl, cap, ctypes.byref(n)))
-        return [dict(name=names[i].decode(), ms=float(ms[i]), calls=int(calls[i]), flops=float(fl[i])) for i in range(n.value)]
+            check(self.lib.ccn_train_profile_read(self.h, names, ms, calls, fl, by, cap, ctypes.byref(n)))
+        return [dict(name=names[i].decode(), ms=float(ms[i]), calls=int(calls[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(n.value)]
 
 
 def mse_loss_grad(eps: torch.Tensor, target: torch.Tensor, want_grad: bool = True):

@@ -64,7 +64,7 @@ struct TT {                                     // an NHWC activation and the pa
 enum { TF_PACK = 0, TF_COND, TF_CONV_FWD, TF_GN_STATS, TF_PREACT, TF_CONV_DGRAD, TF_WGRAD, TF_WGRAD_REDUCE, TF_BIAS, TF_GN_BWD, TF_SMALL, TF_COUNT };
 const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd", "conv_forward", "gn_stats", "gn_silu_prepass", "conv_data_grad", "conv_weight_grad",
                                         "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
-struct Mark { int fam; hipEvent_t ev; double flops; };
+struct Mark { int fam; hipEvent_t ev; double flops, bytes; };
 
 struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; PackDesc* packs = nullptr; int n_packs = 0; };
 
@@ -277,13 +277,13 @@ struct Walk {
         : tr(t), B(B_), H(H_), W(W_), base((char*)ws), launch(l), st(s), P(p), Gd(g) {}
 
     // profiling: the launches that follow belong to family `fam` (flops: their algorithmic work); fam < 0 closes the sequence
-    void mark(int fam, double flops = 0.0)
+    void mark(int fam, double flops = 0.0, double bytes = 0.0)
     {
         if (!launch || !tr->profiling) return;
         if (tr->ev_used == tr->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; tr->ev_pool.push_back(e); }
         hipEvent_t e = tr->ev_pool[tr->ev_used++];
         if (hipEventRecord(e, st) != hipSuccess) return;
-        tr->marks.push_back({fam, e, flops});
+        tr->marks.push_back({fam, e, flops, bytes});
     }
     // fork: the side stream continues from this point of the main stream; join: the main stream waits for everything on the side
     hipStream_t wg_stream = nullptr;
@@ -375,7 +375,7 @@ struct Walk {
     bool preact(const TT& t, const float2* ab, const TT& out)
     {
         if (!launch) return true;
-        mark(TF_PREACT);
+        mark(TF_PREACT, 0.0, 2.0 * B * t.H * t.W * t.C * tr->elem);
         return ok(launch_gn_act(tr->cfg.dtype, t.p, ab, out.p, B, t.H * t.W, t.C, st), "gn_act");
     }
     bool gn_fwd(const TT& t, const TNorm& n, float2*& ab, float2*& stats)
@@ -523,7 +523,8 @@ struct Walk {
         float2* gstat = (float2*)take((size_t)B * G * sizeof(float2));
         if (!launch) return true;
         const int dt = tr->cfg.dtype;
-        mark(TF_GN_BWD);
+        // algorithmic HBM bytes: pass 1 reads x and dA, pass 2 reads them again (+ the residual gradient) and writes dx
+        mark(TF_GN_BWD, 0.0, (double)B * HW * x.C * tr->elem * (addend ? 6.0 : 5.0));
         if (!ok(launch_gn_bwd_reduce(dt, x.p, dA, ab, stats, scr_gn, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_reduce")) return false;
         if (!ok(launch_gn_bwd_finalize(scr_gn, gg.nblk, B, x.C, cpg, G, (double)cpg * HW, par(n.pg), gstat, grad(n.pg), grad(n.pb), st), "gn_bwd_finalize")) return false;
         if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, scr_film, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))
@@ -799,18 +800,18 @@ int ccn_train_profile_enable(ccn_trainer_t tr, int32_t on)
     return CCN_OK;
 }
 
-int ccn_train_profile_read(ccn_trainer_t tr, const char** names, float* ms, int32_t* calls, double* flops, int32_t cap, int32_t* n)
+int ccn_train_profile_read(ccn_trainer_t tr, const char** names, float* ms, int32_t* calls, double* flops, double* bytes, int32_t cap, int32_t* n)
 {
-    if (!tr || !names || !ms || !calls || !flops || !n) return tfail(CCN_EINVAL, "null argument");
+    if (!tr || !names || !ms || !calls || !flops || !bytes || !n) return tfail(CCN_EINVAL, "null argument");
     if (cap < TF_COUNT) return tfail(CCN_EINVAL, "cap too small");
     if (hipDeviceSynchronize() != hipSuccess) return tfail(CCN_EHIP, "hipDeviceSynchronize failed");
-    for (int f = 0; f < TF_COUNT; ++f) { names[f] = kTrainFamilies[f]; ms[f] = 0.f; calls[f] = 0; flops[f] = 0.0; }
+    for (int f = 0; f < TF_COUNT; ++f) { names[f] = kTrainFamilies[f]; ms[f] = 0.f; calls[f] = 0; flops[f] = 0.0; bytes[f] = 0.0; }
     for (size_t i = 0; i + 1 < tr->marks.size(); ++i) {
         const Mark& m = tr->marks[i];
         if (m.fam < 0) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, m.ev, tr->marks[i + 1].ev) != hipSuccess) return tfail(CCN_EHIP, "hipEventElapsedTime failed");
-        ms[m.fam] += t; calls[m.fam] += 1; flops[m.fam] += m.flops;
+        ms[m.fam] += t; calls[m.fam] += 1; flops[m.fam] += m.flops; bytes[m.fam] += m.bytes;
     }
     *n = TF_COUNT;
     tr->marks.clear(); tr->ev_used = 0;

@@ -285,7 +285,8 @@ GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
     g.nslb = nslb; g.zblocks = nsl / nslb; g.pstep = 256 / nslb;
     // pixels per workgroup: at least 256 workgroups per sample (the 32-pixel level would otherwise run on 8), at most 32 passes
     int iters = HW / (g.pstep * 256);
-    iters = iters < 1 ? 1 : (iters > 32 ? 32 : iters);
+    static const int cap = getenv("CCN_GNB_ITERS") ? atoi(getenv("CCN_GNB_ITERS")) : 32;
+    iters = iters < 1 ? 1 : (iters > cap ? cap : iters);
     g.ppb = g.pstep * iters;
     g.nblk = (HW + g.ppb - 1) / g.ppb;
     return g;

@@ -189,11 +189,12 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Per-family timing of the training step (HIP events on the stream the launches go to): enable, run steps, read.
- * names/ms/calls/flops: arrays of `cap` (>= 16) entries; flops = algorithmic conv FLOPs of the family's launches.
+ * names/ms/calls/flops/bytes: arrays of `cap` (>= 16) entries; flops = algorithmic conv FLOPs of the family's launches,
+ * bytes = algorithmic HBM bytes of the bandwidth-bound families (0 for the others).
  * Reading synchronises the device and resets the counters. */
 int ccn_train_profile_enable(ccn_trainer_t tr, int32_t on);
 int ccn_train_profile_read(ccn_trainer_t tr, const char** names, float* ms, int32_t* calls, double* flops,
-                           int32_t cap, int32_t* n);
+                           double* bytes, int32_t cap, int32_t* n);
 
 /* F.mse_loss(eps_hat, noise) (train/diffusion_train.py:124) and its gradient: *loss_dev = mean((eps - target)^2),
  * d_eps_dev = 2 (eps - target) / n (may be NULL).  scratch_dev: at least 1024 floats. */
