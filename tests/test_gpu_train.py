@@ -242,3 +242,43 @@ def test_train_diffusion_entry_point_on_a_synthetic_store(tmp_path):
     losses = [float(ln.split("loss=")[1]) for ln in lines if "epoch" in ln]
     assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < losses[0], lines
     assert any("clip_w" in ln for ln in lines)
+
+
+def test_bf16_step_on_the_persistent_kernel_with_ragged_tiles():
+    """Batch 4 at 136 x 200 with base 128: enough 8-row tiles that the forward and data-gradient 3x3 convs of the first level run on
+    the persistent register-weight kernel (fragment layout packed on the device), with partial tiles on every edge.  bf16 mode
+    against the fp32 mode of the same library."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2)))
+    B, H, W = 4, 136, 200
+    g = torch.Generator("cpu").manual_seed(33)
+    x_t = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.tensor([3, 333, 666, 999]); target = torch.randn((B, 3, H, W), generator=g)
+    l32, g32, e32 = grads_via_autograd(make_net(sd, 128, (1, 2)), x_t, z, t, target)
+    l16, g16, e16 = grads_via_autograd(make_net(sd, 128, (1, 2), dtype="bf16"), x_t, z, t, target)
+    assert float((e16 - e32).abs().max()) < 2e-2
+    worst = ("", 1.0)
+    for k, r in g32.items():
+        a = g16[k].double().flatten(); b = r.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        if cos < worst[1]:
+            worst = (k, cos)
+        assert cos > 0.97 and 0.9 < float(a.norm() / (b.norm() + 1e-30)) < 1.1, (k, cos)
+    print(f"bf16 on the persistent kernel, ragged tiles: worst cosine {worst[1]:.4f} ({worst[0]})")
+
+
+def test_c4_architecture_gradients_fp32():
+    """BASELINE configs[3]'s architecture (base 192, (1,2,2,4): 24/48/96/384 channels per group, 3072-channel bottleneck whose
+    GroupNorm passes span several channel blocks and which the pre-pass kernel cannot take) at 32 px, batch 1: every gradient
+    against the oracle."""
+    spec = synth.unet_param_spec(512, 192, (1, 2, 2, 4))
+    sd = synth.synth_state_dict(spec)
+    g = torch.Generator("cpu").manual_seed(44)
+    x_t = torch.randn((1, 3, 32, 32), generator=g); z = torch.from_numpy(synth.synth_z(1)); t = torch.tensor([512])
+    target = torch.randn((1, 3, 32, 32), generator=g)
+    net = make_net(sd, 192, (1, 2, 2, 4))
+    loss, grads, eps = grads_via_autograd(net, x_t, z, t, target)
+    del net
+    torch.cuda.empty_cache()
+    rloss, rgrads, reps = ref_train.loss_and_grads(ref_unet.as_torch_sd(sd), x_t, z, t, target)
+    assert abs(float(loss) - float(rloss)) < 1e-5 * max(1.0, float(rloss))
+    check_grads(grads, rgrads, 5e-4, "fp32 C4 architecture 1x32x32")
