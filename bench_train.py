@@ -82,7 +82,7 @@ def main() -> None:
     z = torch.from_numpy(synth.synth_z(world * B)[rank * B:rank * B + B]).to(dev)
 
     def step():
-        return train_step(net, sch, opt, x0, z, ddp=world > 1)
+        return train_step(net, sch, opt, x0, z, ddp=world > 1, graph=os.environ.get("CCN_TRAIN_GRAPH", "0") == "1")
 
     def fence():
         torch.cuda.synchronize()

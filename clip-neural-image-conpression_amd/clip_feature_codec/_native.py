@@ -57,6 +57,7 @@ SIGNATURES = {
     "ccn_train_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
     "ccn_train_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_train_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "ccn_train_set_graph": (c_i32, [c_vp, c_i32]),
     "ccn_train_profile_enable": (c_i32, [c_vp, c_i32]),
     "ccn_train_profile_read": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f32), ctypes.POINTER(c_i32),
                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
@@ -315,12 +316,17 @@ class NativeTrainer:
             self._ws[key] = ws
         return ws
 
-    def forward(self, flat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    def set_graph(self, on: bool) -> None:
+        """Capture / replay forward and backward as hipGraphs (callers with fixed buffer addresses only)."""
+        check(self.lib.ccn_train_set_graph(self.h, 1 if on else 0))
+
+    def forward(self, flat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, C, H, W = x.shape
         if C != self.img_ch or z.shape != (B, self.z_dim) or t.shape != (B,) or flat.numel() != self.total:
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, z {tuple(z.shape)}, t {tuple(t.shape)}, params {flat.numel()}")
         ws = self.workspace(B, H, W)
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
         with torch.cuda.device(x.device):
             check(self.lib.ccn_train_forward(self.h, flat.data_ptr(), x.data_ptr(), z.data_ptr(), t.data_ptr(), out.data_ptr(),
                                              B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))
@@ -346,13 +352,15 @@ class NativeTrainer:
         return [dict(name=names[i].decode(), ms=float(ms[i]), calls=int(calls[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(n.value)]
 
 
-def mse_loss_grad(eps: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
+def mse_loss_grad(eps: torch.Tensor, target: torch.Tensor, want_grad: bool = True, bufs=None):
     """F.mse_loss(eps, target) and d loss / d eps in one pass (train/diffusion_train.py:124)."""
     lib = load_library()
     eps = require_dev(eps, "eps"); target = require_dev(target, "target")
-    loss = torch.empty((), dtype=torch.float32, device=eps.device)
-    d = torch.empty_like(eps) if want_grad else None
-    scratch = torch.empty(1024, dtype=torch.float32, device=eps.device)
+    loss, d, scratch = (bufs if bufs is not None else (None, None, None))
+    if loss is None:
+        loss = torch.empty((), dtype=torch.float32, device=eps.device)
+        d = torch.empty_like(eps) if want_grad else None
+        scratch = torch.empty(1024, dtype=torch.float32, device=eps.device)
     with torch.cuda.device(eps.device):
         check(lib.ccn_mse_loss_grad(eps.data_ptr(), target.data_ptr(), eps.numel(), loss.data_ptr(), ptr(d), scratch.data_ptr(),
                                     current_stream(eps.device)))
@@ -385,19 +393,20 @@ def ddim_step(x: torch.Tensor, eps: torch.Tensor, coef: Sequence[float], sigma: 
     return x
 
 
-def _per_sample(fn_name: str, a0: torch.Tensor, a1: torch.Tensor, ca: torch.Tensor, cs: torch.Tensor) -> torch.Tensor:
+def _per_sample(fn_name: str, a0: torch.Tensor, a1: torch.Tensor, ca: torch.Tensor, cs: torch.Tensor, out=None) -> torch.Tensor:
     lib = load_library()
     a0 = require_dev(a0, "x"); a1 = require_dev(a1, "y"); ca = require_dev(ca, "a"); cs = require_dev(cs, "s")
     B = a0.shape[0]
-    out = torch.empty_like(a0)
+    if out is None:
+        out = torch.empty_like(a0)
     with torch.cuda.device(a0.device):
         check(getattr(lib, fn_name)(out.data_ptr(), a0.data_ptr(), a1.data_ptr(), ca.data_ptr(), cs.data_ptr(), B,
                                     a0.numel() // B, current_stream(a0.device)))
     return out
 
 
-def q_sample(x0, noise, a, s):
-    return _per_sample("ccn_q_sample", x0, noise, a, s)
+def q_sample(x0, noise, a, s, out=None):
+    return _per_sample("ccn_q_sample", x0, noise, a, s, out)
 
 
 def predict_x0(x_t, eps, a, s):

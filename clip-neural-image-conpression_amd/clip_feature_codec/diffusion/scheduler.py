@@ -87,10 +87,10 @@ class NoiseScheduler:
     def _gather(self, table: torch.Tensor, t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
         return table.to(like.device)[t.to(like.device)].to(torch.float32).contiguous()
 
-    def q_sample(self, x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
-        """x_t = sqrt(ab_t) x0 + sqrt(1-ab_t) noise, per-sample t (scheduler.py:46-49)."""
+    def q_sample(self, x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """x_t = sqrt(ab_t) x0 + sqrt(1-ab_t) noise, per-sample t (scheduler.py:46-49); ``out``: optional result buffer."""
         return _native.q_sample(x0, noise, self._gather(self.sqrt_alphas_cumprod, t, x0),
-                                self._gather(self.sqrt_one_minus_alphas_cumprod, t, x0))
+                                self._gather(self.sqrt_one_minus_alphas_cumprod, t, x0), out)
 
     def predict_x0_from_eps(self, x_t: torch.Tensor, t: torch.Tensor, eps_hat: torch.Tensor) -> torch.Tensor:
         """(x_t - sqrt(1-ab_t) eps) / sqrt(ab_t) (scheduler.py:51-55)."""

@@ -19,7 +19,6 @@ enum PackMode {
     PK_FRAG3 = 7,     // Conv2d 3x3 s1, bf16           -> MFMA fragment order of the persistent kernel (ccn_conv_pr.hip), forward operand
     PK_FRAG3_DG = 8,  // Conv2d 3x3 s1, bf16           -> the same order for the data-gradient operand (taps flipped, N = I, K = O)
 };
-hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s);
 
 // all repacks of one step in ONE launch: descriptor table built once at create time (offsets into the flat parameter buffer)
 struct PackDesc { long long src_off; void* dst; int mode, O, I, taps, Np, Kp; };

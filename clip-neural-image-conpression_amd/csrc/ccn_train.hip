@@ -83,6 +83,11 @@ struct ccn_trainer_s {
     std::vector<Layer> layers;
     int F = 0;
     float* zero_bias = nullptr;
+    // captured hipGraphs of one forward / one backward, keyed by every pointer argument (ccn_train_set_graph)
+    struct TGraph { std::vector<const void*> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    bool use_graph = false;
+    hipStream_t cap_stream = nullptr;
+    std::vector<TGraph> graphs;
     hipStream_t side = nullptr;           // weight gradients run here, beside the data-gradient chain (nothing downstream reads them)
     std::vector<hipEvent_t> sync_pool; size_t sync_used = 0;
     LinDesc* lin_descs = nullptr; int n_lin = 0, max_lin_n = 0;
@@ -93,7 +98,7 @@ struct ccn_trainer_s {
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<Mark> marks;
     // state of the last forward (checked by backward)
-    int fB = 0, fH = 0, fW = 0; void* fws = nullptr; const float* fx = nullptr;
+    int fB = 0, fH = 0, fW = 0; void* fws = nullptr;
 };
 
 namespace {
@@ -663,9 +668,44 @@ int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
     return CCN_OK;
 }
 
+// replay the cached graph for `key`, or capture `body` (which enqueues on the capture stream) and replay it
+template <typename F>
+int run_graphed(ccn_trainer_s* tr, const std::vector<const void*>& key, hipStream_t user, F&& body)
+{
+    for (auto& g : tr->graphs)
+        if (g.key == key) {
+            if (hipGraphLaunch(g.exec, user) != hipSuccess) return tfail(CCN_EHIP, "hipGraphLaunch failed");
+            return CCN_OK;
+        }
+    if (!tr->cap_stream && hipStreamCreateWithFlags(&tr->cap_stream, hipStreamNonBlocking) != hipSuccess) return tfail(CCN_EHIP, "capture stream");
+    if (hipStreamBeginCapture(tr->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return tfail(CCN_EHIP, "hipStreamBeginCapture failed");
+    std::string err;
+    const bool good = body(tr->cap_stream, err);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(tr->cap_stream, &graph);
+    if (!good) { if (graph) (void)hipGraphDestroy(graph); return tfail(CCN_EHIP, err); }
+    if (ce != hipSuccess) return tfail(CCN_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    ccn_trainer_s::TGraph g; g.key = key; g.graph = graph;
+    if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); return tfail(CCN_EHIP, "hipGraphInstantiate failed"); }
+    if (tr->graphs.size() >= 8) {
+        (void)hipGraphExecDestroy(tr->graphs.front().exec); (void)hipGraphDestroy(tr->graphs.front().graph);
+        tr->graphs.erase(tr->graphs.begin());
+    }
+    tr->graphs.push_back(g);
+    if (hipGraphLaunch(g.exec, user) != hipSuccess) return tfail(CCN_EHIP, "hipGraphLaunch failed");
+    return CCN_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ccn_train_set_graph(ccn_trainer_t tr, int32_t on)
+{
+    if (!tr) return tfail(CCN_EINVAL, "null handle");
+    tr->use_graph = on != 0;
+    return CCN_OK;
+}
 
 int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
 {
@@ -718,6 +758,8 @@ int ccn_train_destroy(ccn_trainer_t tr)
     if (!tr) return CCN_OK;
     for (void* p : tr->allocs) (void)hipFree(p);
     for (hipEvent_t e : tr->ev_pool) (void)hipEventDestroy(e);
+    for (auto& g : tr->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    if (tr->cap_stream) (void)hipStreamDestroy(tr->cap_stream);
     for (hipEvent_t e : tr->sync_pool) (void)hipEventDestroy(e);
     if (tr->side) (void)hipStreamDestroy(tr->side);
     delete tr;
@@ -762,12 +804,24 @@ int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_
     if (rc) return rc;
     if (!workspace_dev || ((uintptr_t)workspace_dev & 255)) return tfail(CCN_EWORKSPACE, "workspace must be non-null and 256-byte aligned");
     if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(si.total));
-    Walk w(tr, B, H, W, workspace_dev, true, (hipStream_t)stream, params_dev, nullptr);
-    w.place_scratch(si);
-    w.shape_packs = si.packs; w.n_shape_packs = si.n_packs;
-    if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) return tfail(CCN_EHIP, w.err);
-    w.mark(-1);
-    tr->fB = B; tr->fH = H; tr->fW = W; tr->fws = workspace_dev; tr->fx = x_t_dev;
+    auto body = [&](hipStream_t st, std::string& err) {
+        Walk w(tr, B, H, W, workspace_dev, true, st, params_dev, nullptr);
+        w.place_scratch(si);
+        w.shape_packs = si.packs; w.n_shape_packs = si.n_packs;
+        if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) { err = w.err; return false; }
+        w.mark(-1);
+        return true;
+    };
+    if (tr->use_graph && !tr->profiling) {
+        const std::vector<const void*> key = {(const void*)1, params_dev, x_t_dev, z_dev, t_dev, eps_dev, workspace_dev, (const void*)(uintptr_t)B,
+                                              (const void*)(uintptr_t)H, (const void*)(uintptr_t)W};
+        rc = run_graphed(tr, key, (hipStream_t)stream, body);
+        if (rc) return rc;
+    } else {
+        std::string err;
+        if (!body((hipStream_t)stream, err)) return tfail(CCN_EHIP, err);
+    }
+    tr->fB = B; tr->fH = H; tr->fW = W; tr->fws = workspace_dev;
     return CCN_OK;
 }
 
@@ -781,14 +835,23 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
     int rc = shape_info(tr, B, H, W, &si);
     if (rc) return rc;
     if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small");
-    Walk w(tr, B, H, W, workspace_dev, false, (hipStream_t)stream, params_dev, grads_dev);
-    w.place_scratch(si);
-    if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) return tfail(CCN_EHIP, w.err);
-    w.launch = true;
-    tr->sync_used = 0;
-    if (!w.backward(x_t_dev, z_dev, d_eps_dev)) return tfail(CCN_EHIP, w.err);
-    if (!w.join_side()) return tfail(CCN_EHIP, w.err);
-    w.mark(-1);
+    auto body = [&](hipStream_t st, std::string& err) {
+        Walk w(tr, B, H, W, workspace_dev, false, st, params_dev, grads_dev);
+        w.place_scratch(si);
+        if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) { err = w.err; return false; }
+        w.launch = true;
+        tr->sync_used = 0;
+        if (!w.backward(x_t_dev, z_dev, d_eps_dev) || !w.join_side()) { err = w.err; return false; }
+        w.mark(-1);
+        return true;
+    };
+    if (tr->use_graph && !tr->profiling) {
+        const std::vector<const void*> key = {(const void*)2, params_dev, grads_dev, x_t_dev, z_dev, d_eps_dev, workspace_dev, (const void*)(uintptr_t)B,
+                                              (const void*)(uintptr_t)H, (const void*)(uintptr_t)W};
+        return run_graphed(tr, key, (hipStream_t)stream, body);
+    }
+    std::string err;
+    if (!body((hipStream_t)stream, err)) return tfail(CCN_EHIP, err);
     return CCN_OK;
 }
 

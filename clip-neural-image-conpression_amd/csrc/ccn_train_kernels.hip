@@ -1,7 +1,7 @@
 // gfx950 kernels of the training step (train/diffusion_train.py:119-124,137-140): the backward pass of CLIPCondUNet.forward.
 //
 // The data gradients of the convolutions are convolutions again and run on the forward implicit-GEMM kernels with
-// re-packed weights (pack_w_kernel): 3x3 s1 -> 3x3 s1 with flipped taps; 3x3 s2 -> the ConvTranspose kernel with a
+// re-packed weights (pack_group_kernel): 3x3 s1 -> 3x3 s1 with flipped taps; 3x3 s2 -> the ConvTranspose kernel with a
 // zero-padded 4x4 kernel; ConvTranspose 4x4 s2 -> the stride-2 kernel run with 16 taps.  New here:
 //   wgrad_kernel         dW[tap][co][ci] = sum over pixels dY[p][co] * act(GN(x))[p + d_tap][ci]: the contraction runs over
 //                        PIXELS, so with channel-contiguous (NHWC) tiles in LDS each lane of v_mfma_f32_32x32x2_f32 reads one
@@ -51,34 +51,6 @@ __device__ __forceinline__ void ab_of(const float* abf, int c, float& a, float& 
 }  // namespace
 
 // ---- weight repacking --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void pack_w_kernel(const float* __restrict__ w, T* __restrict__ dst, int mode, int O, int I, int taps, int Np, int Kp)
-{
-    const size_t total = (size_t)taps * Np * Kp;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % Kp), n = (int)((idx / Kp) % Np), t = (int)(idx / ((size_t)Kp * Np));
-        float v = 0.f;
-        switch (mode) {
-            case PK_CONV3: if (n < O && k < I) v = w[((size_t)n * I + k) * 9 + t]; break;
-            case PK_CONVT: if (n < O && k < I) v = w[((size_t)k * O + n) * 16 + t]; break;
-            case PK_DG3S1: if (n < I && k < O) v = w[((size_t)k * I + n) * 9 + (8 - t)]; break;
-            case PK_DG3S2: { const int ky = t >> 2, kx = t & 3; if (n < I && k < O && ky < 3 && kx < 3) v = w[((size_t)k * I + n) * 9 + ky * 3 + kx]; break; }
-            case PK_DGT: if (n < I && k < O) v = w[((size_t)n * O + k) * 16 + t]; break;
-            case PK_STEM: if (n < O && k < I * 9) v = w[(size_t)n * I * 9 + k]; break;
-            case PK_HEAD_DG: if (n < I && k < O * 9) { const int co = k / 9, tp = k - co * 9; v = w[((size_t)co * I + n) * 9 + (8 - tp)]; } break;
-        }
-        dst[idx] = to_elem<T>(v);
-    }
-}
-hipError_t launch_pack_w(int dtype, const float* w, void* dst, int mode, int O, int I, int taps, int Np, int Kp, hipStream_t s)
-{
-    const size_t total = (size_t)taps * Np * Kp;
-    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == 0) hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid ? grid : 1), dim3(256), 0, s, w, (float*)dst, mode, O, I, taps, Np, Kp);
-    else hipLaunchKernelGGL(pack_w_kernel<__bf16>, dim3(grid ? grid : 1), dim3(256), 0, s, w, (__bf16*)dst, mode, O, I, taps, Np, Kp);
-    return hipGetLastError();
-}
-
 // thread -> one (n, k) pair: its taps are contiguous in the reference layouts (9 or 16 floats), so the reads are whole
 // segments and the writes, one per tap plane, are coalesced across the threads' consecutive k
 template <typename T>

@@ -188,6 +188,11 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
                        const float* z_dev, const float* d_eps_dev, int32_t B, int32_t H, int32_t W,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* on != 0: ccn_train_forward / ccn_train_backward capture their launch sequence into a hipGraph the first time they see a set of
+ * pointer arguments (parameters, gradients, inputs, outputs, workspace) and replay it afterwards -- for callers that keep their
+ * buffers at fixed addresses (a training loop with static input / output tensors).  Off by default. */
+int ccn_train_set_graph(ccn_trainer_t tr, int32_t on);
+
 /* Per-family timing of the training step (HIP events on the stream the launches go to): enable, run steps, read.
  * names/ms/calls/flops/bytes: arrays of `cap` (>= 16) entries; flops = algorithmic conv FLOPs of the family's launches,
  * bytes = algorithmic HBM bytes of the bandwidth-bound families (0 for the others).

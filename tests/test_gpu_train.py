@@ -136,6 +136,23 @@ def test_fused_loss_and_adamw_match_oracle_over_three_steps():
     assert net.train_state().fp.intact()
 
 
+def test_graph_replay_of_forward_and_backward_matches_plain_launches():
+    """train_step(graph=True): captured hipGraphs of the forward and the backward (side-stream branch included) give the same
+    parameters as plain launches after three steps."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    x0, z, t, noise = (torch.from_numpy(GOLD[k]).to(DEV) for k in ("x0", "z", "t", "noise"))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    res = []
+    for graph in (False, True):
+        net = make_net(sd, 32, (1, 2))
+        opt = FusedAdamW(net, lr=2e-4)
+        losses = [float(train_step(net, sch, opt, x0, z, t, noise, graph=graph)) for _ in range(3)]
+        res.append((losses, torch.cat([p.detach().flatten().cpu() for p in net.parameters()])))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5)
+    moved = float((res[0][1] - torch.cat([torch.from_numpy(v).flatten() for k, v in sd.items()])).abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 0.05 * moved
+
+
 def test_torch_optimizer_drop_in_and_eval_after_training():
     """The reference's three lines with torch.optim.AdamW, then .eval() inference sees the updated weights."""
     sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
