@@ -351,8 +351,17 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float2* __re
         const int c = c0 + cl;
         const bool valid = c < (g + 1) * cpg;
         float p1 = 0.f, p2 = 0.f;
-        if (valid)
-            for (int k = rl; k < nblk; k += RL) { const float2 v = part[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
+        if (valid) {
+            int k = rl;
+            for (; k + 7 * RL < nblk; k += 8 * RL) {                  // eight loads in flight, fixed order
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[((size_t)b * nblk + k + u * RL) * C + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { p1 += v[u].x; p2 += v[u].y; }
+            }
+            for (; k < nblk; k += RL) { const float2 v = part[((size_t)b * nblk + k) * C + c]; p1 += v.x; p2 += v.y; }
+        }
         red[rl][cl][0] = p1; red[rl][cl][1] = p2;
         __syncthreads();
         if (rl == 0 && valid) {
