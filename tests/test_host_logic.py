@@ -134,3 +134,32 @@ def test_sharding_and_aggregate():
     rows = np.array([[30.0, 0.9, np.nan, np.nan], [20.0, np.nan, np.nan, np.nan]])
     agg = cli_eval.aggregate(rows)
     assert agg["psnr"] == 25.0 and agg["ssim"] == 0.9 and np.isnan(agg["lpips"])
+
+
+def test_store_dataset_items_follow_the_reference_recipe(tmp_path, synth):
+    """StoreDataset (train/diffusion_train.py:36-60 of the reference): image -> RGB, bicubic resize, /127.5 - 1, CHW fp32;
+    embedding -> dequantised with codec_meta and L2-normalised.  Host logic only (PIL + numpy + libzstd)."""
+    from PIL import Image
+    from clip_feature_codec.train.diffusion_train import StoreDataset, total_variation
+    store = tmp_path / "store"
+    manifest = synth.write_synth_store(store, 3, 24, write_clp=bitstream.write_bitstream)
+    ds = StoreDataset(store, out_size=16)
+    assert len(ds) == 3
+    img, z = ds[1]
+    assert img.shape == (3, 16, 16) and img.dtype == torch.float32 and z.shape == (512,) and z.dtype == torch.float32
+    ref_img = np.array(Image.open(manifest[1]["image"]).convert("RGB").resize((16, 16), Image.BICUBIC)).astype(np.float32) / 127.5 - 1.0
+    assert np.array_equal(img.numpy(), ref_img.transpose(2, 0, 1))
+    meta = np.load(store / "codec_meta.npz")
+    q = bitstream.read_bitstream(manifest[1]["bitstream"])
+    zz = q.astype(np.float32) * meta["scale"].astype("float32") + meta["zero"].astype("float32")
+    zz = zz / max(np.linalg.norm(zz), 1e-9)
+    assert np.allclose(z.numpy(), zz, atol=1e-7) and abs(float(z.norm()) - 1.0) < 1e-5
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    assert float(total_variation(x)) == pytest.approx(5.0 + 1.0)       # |d/dH| = 5, |d/dW| = 1 for a ramp
+
+
+def test_training_forward_refuses_cpu_tensors(tiny_sd):
+    """In .train() mode with gradients enabled the module routes to the library's training path, which has no CPU fallback."""
+    net = CLIPCondUNet(base=32, ch_mult=(1, 2)).train()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net(torch.zeros(1, 3, 32, 32), torch.zeros(1, 512), torch.zeros(1, dtype=torch.long))
