@@ -72,7 +72,8 @@ struct WgArgs {
     __host__ __device__ int tapinfo_dx(int i) const { return ((tapinfo[i] >> 2) & 3) - 1; }
     __host__ __device__ int tapinfo_w(int i) const { return tapinfo[i] >> 4; }
 };
-int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout);
+// concurrent: the launch shares the GPU with the main stream's kernels (side stream), so it asks for fewer workgroups
+int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout, bool concurrent);
 hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s);
 hipError_t wgrad_prepare();
 // grads[(o*I + i)*taps + t] (Conv2d) or grads[(i*O + o)*taps + t] (ConvTranspose2d) += sum over splits

@@ -293,11 +293,15 @@ struct Walk {
     // fork: the side stream continues from this point of the main stream; join: the main stream waits for everything on the side
     hipStream_t wg_stream = nullptr;
     const PackDesc* shape_packs = nullptr; int n_shape_packs = 0;
-    bool fork_side()
+    bool side_active() const
     {
         static const bool off_ = getenv("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
+        return !off_ && !tr->profiling && tr->side != nullptr;
+    }
+    bool fork_side()
+    {
         wg_stream = st;
-        if (off_ || tr->profiling || !tr->side) return true;
+        if (!side_active()) return true;
         if (tr->sync_used == tr->sync_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return true; tr->sync_pool.push_back(e); }
         hipEvent_t e = tr->sync_pool[tr->sync_used++];
         if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) { err = "stream fork failed"; return false; }
@@ -504,9 +508,10 @@ struct Walk {
         a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = Cout;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps; a.taps_w = kind == KIND_CT4 ? 16 : (kind == KIND_STEM ? 1 : 9);
         a.n_ty = ceil_div(g.MH, 4); a.n_tx = ceil_div(g.MW, 32);
-        a.nsplit = wgrad_nsplit(tr->cfg.dtype, kind, B, g.MH, g.MW, Cin, Cout);
+        const int ns_alone = wgrad_nsplit(tr->cfg.dtype, kind, B, g.MH, g.MW, Cin, Cout, false), ns_conc = wgrad_nsplit(tr->cfg.dtype, kind, B, g.MH, g.MW, Cin, Cout, true);
+        a.nsplit = side_active() ? ns_conc : ns_alone;
         fill_taps(a.tapinfo, kind, false);
-        want(need.scr_wg, (size_t)a.nsplit * a.taps_w * Cout * Cin * 4);
+        want(need.scr_wg, (size_t)(ns_alone > ns_conc ? ns_alone : ns_conc) * a.taps_w * Cout * Cin * 4);
         if (!launch) return true;
         if (!fork_side()) return false;
         mark(TF_WGRAD, 2.0 * B * g.Hout * g.Wout * (double)Cov * (kind == KIND_CT4 ? 4 : (kind == KIND_STEM ? 1 : 9)) * Civ);

@@ -1008,7 +1008,7 @@ hipError_t wgrad_prepare()
         }
     return hipSuccess;
 }
-int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
+int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout, bool concurrent)
 {
     size_t lds; int nt, kt;
     (void)wgrad_pick(dtype, kind, &lds, &nt, &kt);
@@ -1017,7 +1017,10 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout)
     const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
     static const int target_bf16 = getenv("CCN_WGRAD_WGS") ? atoi(getenv("CCN_WGRAD_WGS")) : 512;
     const bool ws = dtype == 1 && lds == wgrad_bf16_ws_lds();
-    static const int target_ws = getenv("CCN_WGRAD_WS_WGS") ? atoi(getenv("CCN_WGRAD_WS_WGS")) : 256;
+    // one workgroup per CU when the kernel has the GPU to itself; when it runs on the side stream next to the data-gradient chain,
+    // ~100 workgroups: measured 6.46 ms per step at 96, 6.51 at 128, 7.08 at 256 (the main-stream kernels get the other CUs)
+    static const int env_ws = getenv("CCN_WGRAD_WS_WGS") ? atoi(getenv("CCN_WGRAD_WS_WGS")) : 0;
+    const int target_ws = env_ws > 0 ? env_ws : (concurrent ? 96 : 256);
     int ns = ((ws ? target_ws : (dtype == 1 ? target_bf16 : 768)) + groups - 1) / groups;     // 1 (warp-specialised) or 2-3 workgroups per CU
     if (ns > tiles) ns = tiles;
     if (ns >= 8) ns &= ~7;                                        // whole XCD rounds (see the kernels' block mapping)
