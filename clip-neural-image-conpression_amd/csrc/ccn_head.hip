@@ -7,7 +7,7 @@
 //     out[p][co]       = bias[co] + sum_tap ( G[p + d_tap][tap*3 + co] + S[tap*3 + co] )   over the taps inside the image
 // with the GroupNorm affine folded into the weights per SAMPLE: W'[c][n] = a_b[c] W[c][n], S[n] = sum_c c_b[c] W[c][n]
 // (head_prep_kernel, which replaces the gn_finalize launch of out_norm).  A workgroup computes G for the 10 x 34 halo
-// of its 8 x 32 output tile straight from global memory (input read once, 67 MB at C2), parks it in LDS as fp32 and then
+// of its 8 x 32 output tile straight from global memory (input read once, 134 MB at C2 / batch 8), parks it in LDS as fp32 and then
 // every thread gathers the 27 terms of its pixel and applies the update.  HBM-bound instead of LDS/latency-bound.
 #include "ccn_device.h"
 

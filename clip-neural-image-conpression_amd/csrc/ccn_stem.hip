@@ -1,7 +1,7 @@
 // Stem convolution (models/unet.py:55,88: Conv2d(img_ch, base, 3, padding=1) on the NCHW fp32 image) for the bf16 mode.
 //
 // K = img_ch*9 = 27 is one MFMA K-block (32): the contraction is 2 x v_mfma_f32_32x32x16_bf16 per 32 pixels x 32 channels
-// and costs nothing; the layer is bound by the 128 x H x W NHWC tensor it WRITES (67 MB at C2 / batch 8) and by the VALU
+// and costs nothing; the layer is bound by the 128 x H x W NHWC tensor it WRITES (134 MB at C2 / batch 8) and by the VALU
 // work around it.  The generic implicit-GEMM kernel staged an im2col tile through LDS and transposed the result through
 // LDS again (112 us, 0.6 TB/s).  Here only the output transpose touches LDS:
 //   * the weights (A operand, [channel][k]) sit in registers for the whole kernel, host-packed in fragment order, with the
