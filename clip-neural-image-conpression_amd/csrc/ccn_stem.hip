@@ -3,7 +3,7 @@
 // K = img_ch*9 = 27 is one MFMA K-block (32): the contraction is 2 x v_mfma_f32_32x32x16_bf16 per 32 pixels x 32 channels
 // and costs nothing; the layer is bound by the 128 x H x W NHWC tensor it WRITES (134 MB at C2 / batch 8) and by the VALU
 // work around it.  The generic implicit-GEMM kernel staged an im2col tile through LDS and transposed the result through
-// LDS again (112 us, 0.6 TB/s).  Here only the output transpose touches LDS:
+// LDS again (112 us, 1.2 TB/s).  Here only the output transpose touches LDS:
 //   * the weights (A operand, [channel][k]) sit in registers for the whole kernel, host-packed in fragment order, with the
 //     bias folded in as k = 27 against a constant-one im2col element;
 //   * a lane builds its im2col fragment (B operand: pixel r, k = 16s + 8h .. +7) with 16 masked 4-byte loads straight from
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
         const bool pv = x < W;
         const float mk = pv ? 1.0f : 0.0f;
         // accumulators -> the wave's LDS strip [32 pixels][C bf16 (+16 B pad)] -> 16-byte stores, 256 contiguous bytes per pixel:
-        // direct 8-byte stores from the accumulator layout reached only 1.3 TB/s (32 scattered 16-byte pieces per instruction)
+        // direct 8-byte stores from the accumulator layout reached only 2.6 TB/s (32 scattered 16-byte pieces per instruction)
         unsigned char* const strip = tr + wave * (32 * TRP);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
