@@ -57,6 +57,7 @@ SIGNATURES = {
     "ccn_train_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
     "ccn_train_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_train_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "ccn_train_backward_bucketed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp, c_i64, c_vp, c_vp]),
     "ccn_train_set_graph": (c_i32, [c_vp, c_i32]),
     "ccn_train_profile_enable": (c_i32, [c_vp, c_i32]),
     "ccn_train_profile_read": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f32), ctypes.POINTER(c_i32),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "ccn_last_error": (ctypes.c_char_p, []),
     "ccn_version": (ctypes.c_char_p, []),
 }
+
+GRAD_READY_CB = ctypes.CFUNCTYPE(None, c_vp, c_i64, c_i64)
 
 _lib = None
 
@@ -332,9 +335,26 @@ class NativeTrainer:
                                              B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))
         return out
 
-    def backward(self, flat: torch.Tensor, gflat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, d_eps: torch.Tensor) -> None:
+    def backward(self, flat: torch.Tensor, gflat: torch.Tensor, x: torch.Tensor, z: torch.Tensor, d_eps: torch.Tensor,
+                 bucket_cb=None, bucket_floats: int = 6 << 20) -> None:
+        """``bucket_cb(lo, hi)``: called as soon as ``gflat[lo:hi]`` is complete in stream order (ccn_train_backward_bucketed)."""
         B, C, H, W = x.shape
         ws = self.workspace(B, H, W)
+        if bucket_cb is not None:
+            errs = []
+
+            def tramp(_user, lo, hi):
+                try:
+                    bucket_cb(int(lo), int(hi))
+                except BaseException as exc:          # never unwind through the C frame
+                    errs.append(exc)
+            cfn = GRAD_READY_CB(tramp)
+            with torch.cuda.device(x.device):
+                check(self.lib.ccn_train_backward_bucketed(self.h, flat.data_ptr(), gflat.data_ptr(), x.data_ptr(), z.data_ptr(), d_eps.data_ptr(),
+                                                           B, H, W, ws.ptr, ws.nbytes, current_stream(x.device), int(bucket_floats), cfn, None))
+            if errs:
+                raise errs[0]
+            return
         with torch.cuda.device(x.device):
             check(self.lib.ccn_train_backward(self.h, flat.data_ptr(), gflat.data_ptr(), x.data_ptr(), z.data_ptr(), d_eps.data_ptr(),
                                               B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))

@@ -173,9 +173,19 @@ def train_step(net, sch, opt, x0: torch.Tensor, z: torch.Tensor, t: Optional[tor
     sch.q_sample(sb["x0"], sb["t"], sb["noise"], out=sb["x_t"])
     state.trainer.forward(fp.flat, sb["x_t"], sb["z"], sb["t"], out=sb["eps"])
     loss, d_eps = _native.mse_loss_grad(sb["eps"], sb["noise"], bufs=(sb["loss"], sb["d_eps"], sb["scratch"]))
-    state.trainer.backward(fp.flat, fp.grad, sb["x_t"], sb["z"], d_eps)
-    if ddp:
-        average_gradients(fp.grad)
+    import torch.distributed as dist
+    world = dist.get_world_size() if ddp and dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        # data parallel: the flat gradient buffer is all-reduced bucket by bucket while the backward still runs (RCCL on its own
+        # stream); d_eps is pre-scaled by 1 / world so that the sum is already the mean
+        d_eps.mul_(1.0 / world)
+        works = []
+        state.trainer.backward(fp.flat, fp.grad, sb["x_t"], sb["z"], d_eps,
+                               bucket_cb=lambda lo, hi: works.append(dist.all_reduce(fp.grad[lo:hi], async_op=True)))
+        for w in works:
+            w.wait()
+    else:
+        state.trainer.backward(fp.flat, fp.grad, sb["x_t"], sb["z"], d_eps)
     opt.step()
     opt.zero_grad()
     return loss

@@ -292,6 +292,8 @@ struct Walk {
     }
     // fork: the side stream continues from this point of the main stream; join: the main stream waits for everything on the side
     hipStream_t wg_stream = nullptr;
+    // bucketed backward: cb(user, lo, hi) as soon as the gradients of flat range [lo, hi) are complete in stream order on `st`
+    ccn_grad_ready_cb bucket_cb = nullptr; void* bucket_user = nullptr; long long bucket_floats = 0, hi_pending = 0;
     const PackDesc* shape_packs = nullptr; int n_shape_packs = 0;
     bool side_active() const
     {
@@ -542,6 +544,16 @@ struct Walk {
         if (film_r) return ok(launch_film_bwd_finalize(scr_film, gg.nblk, film_r, tr->F, dfilm_r, film_bias, B, x.C, st), "film_bwd");
         return true;
     }
+    bool flush_bucket(long long lo, bool force)
+    {
+        if (!bucket_cb || !launch) return true;
+        if (!force && hi_pending - lo < bucket_floats) return true;
+        if (lo >= hi_pending) return true;
+        if (!join_side()) return false;
+        bucket_cb(bucket_user, lo, hi_pending);
+        hi_pending = lo;
+        return true;
+    }
     bool lin_bwd(const TLin& l, const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int accumulate)
     {
         if (!launch) return true;
@@ -556,6 +568,8 @@ struct Walk {
         const int td = c.time_dim, dt = c.dtype;
         dfilm = (float*)take((size_t)B * tr->F * 4); dh = (float*)take((size_t)B * td * 4);
         dt1 = (float*)take((size_t)B * td * 16); du0 = (float*)take((size_t)B * td * 16); duz = (float*)take((size_t)B * td * 4);
+        hi_pending = (long long)tr->total;
+        if (launch && bucket_cb && hipMemsetAsync(dh, 0, (size_t)B * td * 4, st) != hipSuccess) { err = "hipMemsetAsync failed"; return false; }
         TT g;                                                  // gradient w.r.t. the current tensor
         std::vector<void*> dskip;                              // gradients waiting at the skip connections (pushed by the up path)
         int ri = (int)rs.size() - 1, di = (int)down_in.size() - 1, ui = (int)up_in.size() - 1;
@@ -606,6 +620,14 @@ struct Walk {
                     TT g1 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c2, g.p, g.H, g.W, g1.p, nullptr)) return false;
                     if (!gn_bwd(s.y, r.n2, s.ab2, s.st2, g1.p, g1.p, true, nullptr, r.film_off, launch ? grad(r.c1.pb) : nullptr)) return false;
+                    if (launch && bucket_cb) {
+                        // bucketed mode: this block's FiLM linears now (side stream) instead of one grouped launch at the end, so that the
+                        // block's whole parameter range is complete when its bucket is handed out
+                        if (!fork_side()) return false;
+                        const LinDesc* d2 = tr->lin_descs + 2 * L.idx;
+                        if (!ok(launch_film_group_dw(Gd, d2, 2, r.C, dfilm, hv, B, td, tr->F, wg_stream), "film_dw")) return false;
+                        if (!ok(launch_film_group_dx(P, d2, 2, dfilm, dh, B, td, tr->F, wg_stream), "film_dx")) return false;
+                    }
                     if (!conv_wgrad(r.c1, s.pre ? s.xa : s.x, s.pre ? nullptr : s.ab1, g1.p, g.H, g.W, true)) return false;
                     TT g2 = new_tensor(r.C, g.H, g.W);
                     if (!conv_dgrad(r.c1, g1.p, g.H, g.W, g2.p, nullptr)) return false;
@@ -630,18 +652,34 @@ struct Walk {
                     break;
                 }
             }
+            if (bucket_cb) {
+                int first = 0;                                  // first parameter of this layer: everything from its offset up is complete
+                switch (L.type) {
+                    case L_HEAD: first = tr->out_norm.pg; break;
+                    case L_UP: first = tr->ups[L.idx].pw; break;
+                    case L_DOWN: first = tr->downs[L.idx].pw; break;
+                    case L_RES: first = tr->res[L.idx].n1.pg; break;
+                    case L_STEM: first = tr->stem.pw; break;
+                }
+                if (L.type != L_STEM && !flush_bucket((long long)tr->params[first].off, false)) return false;
+            }
         }
         // conditioning: film_r = h W_r^T + b_r for every block; h = time_proj(temb(t)) + z_proj(z)
         if (!launch) return true;
         mark(TF_COND);
-        if (hipMemsetAsync(dh, 0, (size_t)B * td * 4, st) != hipSuccess) { err = "hipMemsetAsync failed"; return false; }
-        if (!ok(launch_film_group_dw(Gd, tr->lin_descs, tr->n_lin, tr->max_lin_n, dfilm, hv, B, td, tr->F, st), "film_dw")) return false;
-        if (!ok(launch_film_group_dx(P, tr->lin_descs, tr->n_lin, dfilm, dh, B, td, tr->F, st), "film_dx")) return false;
+        if (bucket_cb) {
+            if (!join_side()) return false;                      // dh was accumulated block by block on the side stream
+        } else {
+            if (hipMemsetAsync(dh, 0, (size_t)B * td * 4, st) != hipSuccess) { err = "hipMemsetAsync failed"; return false; }
+            if (!ok(launch_film_group_dw(Gd, tr->lin_descs, tr->n_lin, tr->max_lin_n, dfilm, hv, B, td, tr->F, st), "film_dw")) return false;
+            if (!ok(launch_film_group_dx(P, tr->lin_descs, tr->n_lin, dfilm, dh, B, td, tr->F, st), "film_dx")) return false;
+        }
         if (!lin_bwd(tr->tp2, dh, td, t1, 4 * td, dt1, 4 * td, 0)) return false;
         if (!ok(launch_silu_bwd(du0, dt1, u0, (int64_t)B * 4 * td, st), "silu_bwd")) return false;
         if (!lin_bwd(tr->tp0, du0, 4 * td, temb, td, nullptr, 0, 0)) return false;
         if (!ok(launch_silu_bwd(duz, dh, uz, (int64_t)B * td, st), "silu_bwd")) return false;
-        return lin_bwd(tr->zp, duz, td, z, c.z_dim, nullptr, 0, 0);
+        if (!lin_bwd(tr->zp, duz, td, z, c.z_dim, nullptr, 0, 0)) return false;
+        return flush_bucket(0, true);
     }
 };
 
@@ -857,6 +895,27 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
     }
     std::string err;
     if (!body((hipStream_t)stream, err)) return tfail(CCN_EHIP, err);
+    return CCN_OK;
+}
+
+int ccn_train_backward_bucketed(ccn_trainer_t tr, const float* params_dev, float* grads_dev, const float* x_t_dev, const float* z_dev, const float* d_eps_dev,
+                                int32_t B, int32_t H, int32_t W, void* workspace_dev, size_t workspace_bytes, void* stream, int64_t bucket_floats,
+                                ccn_grad_ready_cb cb, void* user)
+{
+    if (!tr || !params_dev || !grads_dev || !x_t_dev || !z_dev || !d_eps_dev || !cb) return tfail(CCN_EINVAL, "null argument");
+    if (tr->fB != B || tr->fH != H || tr->fW != W || tr->fws != workspace_dev)
+        return tfail(CCN_ESTATE, "ccn_train_backward_bucketed must follow ccn_train_forward with the same shape and workspace");
+    ShapeInfo si;
+    int rc = shape_info(tr, B, H, W, &si);
+    if (rc) return rc;
+    if (workspace_bytes < si.total) return tfail(CCN_EWORKSPACE, "workspace too small");
+    Walk w(tr, B, H, W, workspace_dev, false, (hipStream_t)stream, params_dev, grads_dev);
+    w.place_scratch(si);
+    if (!w.forward(x_t_dev, z_dev, nullptr, nullptr)) return tfail(CCN_EHIP, w.err);
+    w.launch = true;
+    w.bucket_cb = cb; w.bucket_user = user; w.bucket_floats = bucket_floats > 0 ? bucket_floats : 1;
+    tr->sync_used = 0;
+    if (!w.backward(x_t_dev, z_dev, d_eps_dev) || !w.join_side()) return tfail(CCN_EHIP, w.err);
     return CCN_OK;
 }
 

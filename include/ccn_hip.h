@@ -188,6 +188,18 @@ int ccn_train_backward(ccn_trainer_t tr, const float* params_dev, float* grads_d
                        const float* z_dev, const float* d_eps_dev, int32_t B, int32_t H, int32_t W,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same backward for a data-parallel caller that overlaps the gradient all-reduce with it (DistributedDataParallel's buckets):
+ * cb(user, lo, hi) is called from the calling thread as soon as every gradient in the flat range [lo, hi) (floats) is complete
+ * in stream order on `stream` -- the caller enqueues its collective on that range right there.  Ranges are disjoint, handed out
+ * from the end of the buffer towards its start (the backward visits the layers in reverse registration order), each at least
+ * bucket_floats long except the last, and together cover the whole buffer.  The FiLM linears are then differentiated block by
+ * block instead of in one grouped launch at the end. */
+typedef void (*ccn_grad_ready_cb)(void* user, int64_t lo_float, int64_t hi_float);
+int ccn_train_backward_bucketed(ccn_trainer_t tr, const float* params_dev, float* grads_dev, const float* x_t_dev,
+                                const float* z_dev, const float* d_eps_dev, int32_t B, int32_t H, int32_t W,
+                                void* workspace_dev, size_t workspace_bytes, void* stream, int64_t bucket_floats,
+                                ccn_grad_ready_cb cb, void* user);
+
 /* on != 0: ccn_train_forward / ccn_train_backward capture their launch sequence into a hipGraph the first time they see a set of
  * pointer arguments (parameters, gradients, inputs, outputs, workspace) and replay it afterwards -- for callers that keep their
  * buffers at fixed addresses (a training loop with static input / output tensors).  Off by default. */

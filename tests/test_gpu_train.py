@@ -299,3 +299,61 @@ def test_c4_architecture_gradients_fp32():
     rloss, rgrads, reps = ref_train.loss_and_grads(ref_unet.as_torch_sd(sd), x_t, z, t, target)
     assert abs(float(loss) - float(rloss)) < 1e-5 * max(1.0, float(rloss))
     check_grads(grads, rgrads, 5e-4, "fp32 C4 architecture 1x32x32")
+
+
+def test_bucketed_backward_hands_out_the_whole_buffer_and_the_same_gradients():
+    """ccn_train_backward_bucketed: the gradient-ready ranges are disjoint, descend from the end of the flat buffer, cover it, and the
+    gradients equal those of the plain backward (FiLM linears differentiated block by block instead of grouped)."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    st = net.train_state()
+    x, z, t, noise = (torch.from_numpy(GOLD[k]).to(DEV) for k in ("x_t", "z", "t", "noise"))
+    eps = st.trainer.forward(st.fp.flat, x, z, t)
+    _, d = _native.mse_loss_grad(eps, noise)
+    g_plain = torch.zeros_like(st.fp.flat); g_bucket = torch.zeros_like(st.fp.flat)
+    st.trainer.backward(st.fp.flat, g_plain, x, z, d)
+    ranges = []
+    st.trainer.backward(st.fp.flat, g_bucket, x, z, d, bucket_cb=lambda lo, hi: ranges.append((lo, hi)), bucket_floats=200_000)
+    assert len(ranges) >= 3 and ranges[0][1] == st.trainer.total and ranges[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(ranges, ranges[1:]):
+        assert lo < hi and hi2 == lo and lo2 < hi2
+    assert all(hi - lo >= 200_000 for lo, hi in ranges[:-1])
+    scale = float(g_plain.abs().max())
+    assert float((g_plain - g_bucket).abs().max()) <= 2e-6 * scale
+    with pytest.raises(ZeroDivisionError):                      # an exception inside the callback surfaces after the C call returns
+        st.trainer.backward(st.fp.flat, torch.zeros_like(g_plain), x, z, d, bucket_cb=lambda lo, hi: 1 // 0)
+
+
+def _ddp_rank(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    opt = FusedAdamW(net, lr=2e-4)
+    g = torch.Generator("cpu").manual_seed(9)
+    x0 = torch.rand((4, 3, 32, 32), generator=g) * 2 - 1; z = torch.from_numpy(synth.synth_z(4))
+    t = torch.tensor([10, 400, 700, 990]); noise = torch.randn((4, 3, 32, 32), generator=g)
+    lo, hi = rank * 4 // world, (rank + 1) * 4 // world
+    for _ in range(2):
+        train_step(net, sch, opt, x0[lo:hi].to(DEV), z[lo:hi].to(DEV), t[lo:hi].to(DEV), noise[lo:hi].to(DEV), ddp=world > 1)
+    if rank == 0:
+        np.save(out, torch.cat([p.detach().flatten().cpu() for p in net.parameters()]).numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_with_overlapped_allreduce_equals_single_process(tmp_path):
+    """Two ranks (gloo, both on this GPU) train on half batches with the bucketed backward + asynchronous all-reduce per bucket; after
+    two steps their parameters equal those of one process training on the whole batch."""
+    import torch.multiprocessing as mp
+    _ddp_rank(0, 1, 0, str(tmp_path / "p1.npy"))
+    mp.spawn(_ddp_rank, args=(2, 29571, str(tmp_path / "p2.npy")), nprocs=2, join=True)
+    p1, p2 = np.load(tmp_path / "p1.npy"), np.load(tmp_path / "p2.npy")
+    init = np.concatenate([v.reshape(-1) for v in synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2))).values()])
+    moved = np.abs(p1 - init).max()
+    assert moved > 0 and np.abs(p1 - p2).max() <= 0.05 * moved
