@@ -132,8 +132,8 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
 hipError_t launch_pack_group(int dtype, const float* params, const PackDesc* descs_dev, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (dtype == 0) hipLaunchKernelGGL(pack_group_kernel<float>, dim3(64, n), dim3(256), 0, s, params, descs_dev);
-    else hipLaunchKernelGGL(pack_group_kernel<__bf16>, dim3(64, n), dim3(256), 0, s, params, descs_dev);
+    if (dtype == 0) hipLaunchKernelGGL(pack_group_kernel<float>, dim3(512, n), dim3(256), 0, s, params, descs_dev);
+    else hipLaunchKernelGGL(pack_group_kernel<__bf16>, dim3(512, n), dim3(256), 0, s, params, descs_dev);
     return hipGetLastError();
 }
 
@@ -1041,7 +1041,8 @@ hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed,
+// small layers (few (o, i) pairs, many splits): thread -> one element, eight splits in flight
+__global__ void wgrad_reduce_elem_kernel(const float* __restrict__ part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed,
                                     float* __restrict__ grad)
 {
     const size_t per = (size_t)taps * O * I;
@@ -1062,11 +1063,45 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
         grad[dst] += s;
     }
 }
+// thread -> one (o, i) pair and all its taps: the partial reads are coalesced per tap plane, the gradient writes are the pair's
+// contiguous taps (one thread = 36 or 64 bytes, neighbours adjacent) -- per-tap threads wrote 4 bytes at a 36-byte stride
+template <int TAPS>
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int O, int I, int Ov, int Iv, int transposed,
+                                    float* __restrict__ grad)
+{
+    const size_t plane = (size_t)O * I, per = plane * TAPS;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I), o = (int)(idx / I);
+        if (i >= Iv || o >= Ov) continue;
+        float s[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+        for (int k = 0; k < nsplit; ++k) {                          // fixed order; TAPS loads in flight
+            const float* p = part + (size_t)k * per + idx;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s[t] += p[(size_t)t * plane];
+        }
+        float* dst = grad + (transposed ? ((size_t)i * Ov + o) : ((size_t)o * Iv + i)) * TAPS;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) dst[t] += s[t];
+    }
+}
 hipError_t launch_wgrad_reduce(const float* part, int nsplit, int taps, int O, int I, int Ov, int Iv, int transposed, float* grad, hipStream_t s)
 {
-    const size_t per = (size_t)taps * O * I;
-    const unsigned grid = (unsigned)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, taps, O, I, Ov, Iv, transposed, grad);
+    const size_t plane = (size_t)O * I;
+    if (plane < (size_t)200000) {                                  // not enough pairs to fill the GPU: one thread per element
+        const size_t per = plane * taps;
+        const unsigned ge = (unsigned)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);
+        hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(ge ? ge : 1), dim3(256), 0, s, part, nsplit, taps, O, I, Ov, Iv, transposed, grad);
+        return hipGetLastError();
+    }
+    const unsigned grid = (unsigned)((plane + 255) / 256 < 16384 ? (plane + 255) / 256 : 16384);
+    switch (taps) {
+        case 9: hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, O, I, Ov, Iv, transposed, grad); break;
+        case 16: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, O, I, Ov, Iv, transposed, grad); break;
+        case 1: hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid ? grid : 1), dim3(256), 0, s, part, nsplit, O, I, Ov, Iv, transposed, grad); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
