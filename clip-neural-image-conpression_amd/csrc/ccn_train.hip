@@ -683,7 +683,11 @@ struct Walk {
     }
 };
 
-std::string shape_key(int B, int H, int W) { return std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W); }
+// the kernel choice (tests switch it between handles) decides which repacks a shape needs, so it is part of the key
+std::string shape_key(int B, int H, int W)
+{
+    return std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W) + (conv_pr_selected(1, KIND_C3S1, 128, 8) ? "p" : "n");
+}
 
 int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
 {
