@@ -130,8 +130,7 @@ class FusedAdamW:
         self.steps += 1
         _native.adamw_step(fp.flat, fp.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                            self.weight_decay, self.steps)
-        fp.flat._version  # noqa: B018  (in-place kernel: bump below)
-        fp.flat.add_(0)    # bumps the version counter so that a stale forward is detected
+        fp.flat[:1].add_(0)    # the kernel wrote behind torch's back: bump the (shared) version counter so that a stale forward is detected
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.state.fp.grad.zero_()
