@@ -65,7 +65,12 @@ def main() -> None:
     dev = f"cuda:{local % torch.cuda.device_count()}"
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        # RCCL ("nccl") on a GPU node; CCN_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on one card
+        backend = os.environ.get("CCN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
     _native.load_library()
 
     ch_mult = tuple(int(v) for v in args.ch_mult.split(","))
