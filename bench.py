@@ -6,7 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: ccn_sample of 8 images (256x256, base=128,
-ch_mult=(1,2,2)) through 50 DDIM steps, replayed as one hipGraph, inputs resident in HBM.  Ranks hold
+ch_mult=(1,2,2)) through 50 DDIM steps, replayed as one hipGraph, inputs resident in HBM.  Consecutive steps are
+independent batches (like consecutive batches of cli.eval) and by default TWO are kept in flight per GPU, each on its
+own stream with its own workspace and graph (`--inflight 1` times them strictly one after the other; the line also
+carries that figure as config.value_with_one_step_in_flight); every launch still works on a batch of 8.  Ranks hold
 independent batches (weak scaling, no data-path collective).  Rank 0 prints ONE JSON line with the
 contract fields plus `roofline` (dominant kernel, HIP-event timed in a launch-by-launch pass of the same
 workload) and, at N=1, `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
@@ -43,6 +46,8 @@ def main() -> None:
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--base", type=int, default=128)
     ap.add_argument("--ch-mult", type=str, default="1,2,2")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
+                    help="bench steps (independent batches) kept in flight per GPU, each on its own stream / workspace / graph, as cli.eval does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="most DDIM steps of the CPU-baseline sample (batch 1)")
@@ -83,8 +88,19 @@ def main() -> None:
     x_T = torch.from_numpy(synth.start_noise(idx, S, seed_base=100)).to(dev)
     sampler = DDIMSampler(NoiseScheduler(1000, "cosine", dev), eta=0.0)
 
-    def step():
-        return sampler.sample(net, z, (B, 3, S, S), steps=T, x_T=x_T)
+    # consecutive bench steps are independent batches (as consecutive batches of cli.eval are): step i runs on stream i % inflight with
+    # its own workspace and captured graph, so one batch's kernel tails and launch gaps are filled by the other's work
+    nfl = args.inflight
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+
+    def step(i=0):
+        st = streams[i % nfl]
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            return sampler.sample(net, z, (B, 3, S, S), steps=T, x_T=x_T, slot=i % nfl)
+
+    for i in range(nfl):                                             # plan + graph capture of every slot, outside warm-up and timing
+        step(i)
 
     def fence():
         torch.cuda.synchronize()
@@ -92,13 +108,13 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        x = step()
+    for i in range(args.warmup):
+        x = step(i)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x = step()
+    outs = [step(i) for i in range(args.steps)]
     fence()
+    x = outs[-1]
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -106,6 +122,21 @@ def main() -> None:
         dt = float(tt.item())
     assert torch.isfinite(x).all()
     value = world * B * args.steps / dt
+    # for reference, the same steps strictly one after the other on one stream (what `--inflight 1` times)
+    seq_value = None
+    if nfl > 1:
+        nseq = min(args.steps, 3)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(nseq):
+            step(0)
+        fence()
+        seq_dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([seq_dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            seq_dt = float(tt.item())
+        seq_value = round(world * B * nseq / seq_dt, 3)
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -179,7 +210,8 @@ def main() -> None:
             "config": {"workload": f"{S}px base={args.base} ch_mult={ch_mult} {T}-step DDIM (eta=0), batch={B}/GPU, "
                                    "key-seeded synthetic weights (out.* x0.1), synthetic z / x_T",
                        "global_batch": world * B, "parallelism": f"dp{world} (independent batches, no collective in the loop)",
-                       "graph": "hipGraph, one replay per step"},
+                       "graph": "hipGraph, one replay per step",
+                       "steps_in_flight": nfl, "value_with_one_step_in_flight": seq_value},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

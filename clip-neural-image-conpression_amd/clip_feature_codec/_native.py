@@ -155,7 +155,7 @@ class NativeUNet:
         with torch.cuda.device(self.device):
             check(self.lib.ccn_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
-        self._ws: Dict[Tuple[int, int, int, int], Workspace] = {}
+        self._ws: Dict[Tuple[int, int, int, int, int], Workspace] = {}
 
     def close(self) -> None:
         if getattr(self, "h", None):
@@ -192,8 +192,9 @@ class NativeUNet:
         self._ws.clear()
 
     # -- scratch -----------------------------------------------------------------------------
-    def workspace(self, B: int, H: int, W: int, steps: int) -> Workspace:
-        key = (B, H, W, steps)
+    def workspace(self, B: int, H: int, W: int, steps: int, slot: int = 0) -> Workspace:
+        """``slot``: independent scratch (and, inside the library, plan + captured graph) for callers that keep several batches in flight."""
+        key = (B, H, W, steps, slot)
         ws = self._ws.get(key)
         if ws is None:
             n = c_sz()
@@ -215,7 +216,7 @@ class NativeUNet:
                                        ws.ptr, ws.nbytes, current_stream(x.device)))
         return out
 
-    def sample(self, z: torch.Tensor, x_T: torch.Tensor, ts, coef, use_graph: bool = True) -> torch.Tensor:
+    def sample(self, z: torch.Tensor, x_T: torch.Tensor, ts, coef, use_graph: bool = True, slot: int = 0) -> torch.Tensor:
         import numpy as np
         z = require_dev(z, "z_clip"); x_T = require_dev(x_T, "x_T")
         B, C, H, W = x_T.shape
@@ -226,7 +227,7 @@ class NativeUNet:
             raise ValueError("coef must be (steps, 4)")
         if C != self.img_ch or z.shape != (B, self.z_dim):
             raise ValueError(f"shape mismatch: x_T {tuple(x_T.shape)}, z {tuple(z.shape)}")
-        ws = self.workspace(B, H, W, steps)
+        ws = self.workspace(B, H, W, steps, slot)
         out = torch.empty_like(x_T)
         with torch.cuda.device(x_T.device):
             check(self.lib.ccn_sample(self.h, z.data_ptr(), x_T.data_ptr(), out.data_ptr(), B, H, W, steps,

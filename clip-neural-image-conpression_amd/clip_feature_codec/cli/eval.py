@@ -81,18 +81,36 @@ def aggregate(rows: np.ndarray) -> dict:
 
 
 def evaluate(manifest: List[dict], z_of: Callable[[dict], np.ndarray], reconstruct: Callable, size: int, batch: int,
-             seed: Optional[int], rank: int, world: int, device: str, start_noise_fn: Callable) -> np.ndarray:
-    """Shard, reconstruct in batches, score on the host, gather.  ``reconstruct(z, x_T) -> (b,3,S,S)`` numpy in [-1,1]."""
+             seed: Optional[int], rank: int, world: int, device: str, start_noise_fn: Callable, submit: Optional[Callable] = None,
+             fetch: Optional[Callable] = None) -> np.ndarray:
+    """Shard, reconstruct in batches, score on the host, gather.  ``reconstruct(z, x_T) -> (b,3,S,S)`` numpy in [-1,1].
+
+    With ``submit(z, x_T, slot) -> handle`` / ``fetch(handle) -> numpy`` (the GPU path) two batches are kept in flight: batch k+1 is
+    enqueued on the other stream before batch k's result is waited for -- consecutive batches are independent, and one batch's kernel
+    tails and launch gaps fill with the other's work (80 vs 71 images/s per GPU at C2)."""
     mine = shard_indices(len(manifest), rank, world)
     rows: List[List[float]] = []
     with ThreadPoolExecutor(max_workers=4) as pool:
-        for lo in range(0, len(mine), batch):
+        pending = None                                             # (handle, originals) of the batch still on the GPU
+        def finish(p):
+            recon = fetch(p[0])
+            futs = [pool.submit(metric_row, o.result(), recon[k], device) for k, o in enumerate(p[1])]
+            return [f.result() for f in futs]
+        for bi, lo in enumerate(range(0, len(mine), batch)):
             idx = mine[lo:lo + batch]
             originals = [pool.submit(load_original, manifest[i]["image"], size) for i in idx]
             z = np.concatenate([z_of(manifest[i]) for i in idx], 0)
+            if submit is not None and fetch is not None:
+                handle = submit(z, start_noise_fn(idx, size, seed), bi & 1)
+                if pending is not None:
+                    rows += finish(pending)
+                pending = (handle, originals)
+                continue
             recon = reconstruct(z, start_noise_fn(idx, size, seed))
             futs = [pool.submit(metric_row, o.result(), recon[k], device) for k, o in enumerate(originals)]
             rows += [f.result() for f in futs]
+        if pending is not None:
+            rows += finish(pending)
     local = np.asarray(rows, dtype=np.float64).reshape(len(mine), len(METRIC_KEYS))
     return gather_metric_rows(mine, local, len(manifest), device)
 
@@ -133,8 +151,26 @@ def main(argv=None) -> None:
                                x_T=None if x_T is None else x_T.to(device))
         return x.clamp(-1, 1).cpu().numpy()
 
+    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+
+    def submit(z: np.ndarray, x_T: Optional[torch.Tensor], slot: int):
+        zt = torch.from_numpy(z).to(device)
+        xt = None if x_T is None else x_T.to(device)
+        st = streams[slot]
+        st.wait_stream(torch.cuda.current_stream(device))
+        with torch.no_grad(), torch.cuda.stream(st):
+            x = sampler.sample(net, zt, shape=(zt.shape[0], 3, args.size, args.size), steps=args.steps, x_T=xt, slot=slot).clamp(-1, 1)
+        ev = torch.cuda.Event(); ev.record(st)
+        return x, ev, zt, xt                                       # inputs kept alive until the result is fetched
+
+    def fetch(handle) -> np.ndarray:
+        handle[1].synchronize()
+        return handle[0].cpu().numpy()
+
+    pipelined = args.eta == 0                                      # the fused sampler; eta > 0 draws noise step by step
     rows = evaluate(manifest, lambda rec: load_embedding(Path(rec["bitstream"]), scale, zero), reconstruct,
-                    args.size, args.batch, args.seed, rank, world, device, start_noise)
+                    args.size, args.batch, args.seed, rank, world, device, start_noise,
+                    submit if pipelined else None, fetch if pipelined else None)
     if rank == 0:
         agg = aggregate(rows)
         print(f"Average PSNR: {agg['psnr']:.2f} dB")

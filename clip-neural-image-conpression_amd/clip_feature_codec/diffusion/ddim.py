@@ -33,7 +33,7 @@ class DDIMSampler:
 
     @torch.no_grad()
     def sample(self, model, z_clip: torch.Tensor, shape: tuple, steps: int = 50, cfg_scale: float = 1.0,
-               x_T: Optional[torch.Tensor] = None) -> torch.Tensor:
+               x_T: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         device = z_clip.device
         if device.type != "cuda":
             raise RuntimeError(f"z_clip is on {device}: DDIMSampler (MI355X build) needs a HIP device; no CPU fallback")
@@ -41,7 +41,7 @@ class DDIMSampler:
         coef = self.sch.ddim_coefficients(steps, self.eta)
         x = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
         if self.eta == 0 and hasattr(model, "sample_ddim"):
-            return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph)
+            return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph, slot=slot)
         x = _native.require_dev(x, "x_T").clone()
         for i in range(steps):
             t_b = torch.full((shape[0],), int(ts[i]), device=device, dtype=torch.long)

@@ -34,5 +34,18 @@ for name, fn in (("one batch of 8", whole), ("2 x 4 on two streams", lambda: spl
     for _ in range(5): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print(f"{name}: {dt * 1e3:.2f} ms, {8 / dt:.2f} img/s")
+# two whole batches of 8 in flight on two streams (consecutive batches of an eval loop are independent)
+def two_batches():
+    outs = []
+    for i in range(2):
+        with torch.cuda.stream(streams[i]):
+            outs.append(s.sample(nets[i], z, (8, 3, 256, 256), steps=50, x_T=x_T))
+    return outs
+for _ in range(2):
+    two_batches(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): two_batches()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    print(f"two batches of 8 in flight: {dt * 1e3:.2f} ms per pair, {16 / dt:.2f} img/s")
 a = whole(); b = torch.cat(split(2)); torch.cuda.synchronize()
 print("max abs difference between the two ways:", float((a - b).abs().max()))
