@@ -1,3 +1,4 @@
+"""Compare two .npy dumps (tools/fwd_dump.py): max-abs / mean-abs difference per file."""
 #!/usr/bin/env python3
 import sys, numpy as np
 a, b = np.load(sys.argv[1]), np.load(sys.argv[2])
