@@ -1,5 +1,5 @@
-"""Compare two .npy dumps (tools/fwd_dump.py): max-abs / mean-abs difference per file."""
 #!/usr/bin/env python3
+"""Compare two .npy dumps (tools/fwd_dump.py): max-abs / mean-abs difference per file."""
 import sys, numpy as np
 a, b = np.load(sys.argv[1]), np.load(sys.argv[2])
 d = np.abs(a.astype(np.float64) - b)
