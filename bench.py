@@ -33,6 +33,7 @@ import torch
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"
 
 
 def main() -> None:
@@ -51,7 +52,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="most DDIM steps of the CPU-baseline sample (batch 1)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (bf16 vs the reference's golden / fp32 mode, PSNR delta)")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: start the N ranks ourselves (child processes, before this process touches the GPU)
+    from clip_feature_codec.utils.launch import ensure_ranks, init_process_group, rank_env, collective_device
+    ensure_ranks(args.gpus, str(Path(__file__).resolve()))
 
     import torch.distributed as dist
     from clip_feature_codec import _native
@@ -60,22 +66,21 @@ def main() -> None:
     from clip_feature_codec.diffusion.scheduler import NoiseScheduler
     from clip_feature_codec.diffusion.ddim import DDIMSampler
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank, world, local = rank_env()
+    assert world == args.gpus, (world, args.gpus)                    # ensure_ranks guarantees it
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     dev = f"cuda:{local % torch.cuda.device_count()}"
     torch.cuda.set_device(dev)
+    ranks_seen = 1
     if world > 1:
         # RCCL ("nccl") on a GPU node; CCN_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on one card
-        backend = os.environ.get("CCN_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend)
+        init_process_group(dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                        # every rank really is there: the sum of ones over the group
+        ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} ranks")
     _native.load_library()
 
     ch_mult = tuple(int(v) for v in args.ch_mult.split(","))
@@ -116,13 +121,18 @@ def main() -> None:
     fence()
     t0 = time.perf_counter()
     outs = [step(i) for i in range(args.steps)]
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                                # this rank's own work drained, before waiting for the others
     fence()
     x = outs[-1]
     dt = time.perf_counter() - t0
+    per_rank = [B * args.steps / dt_own]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt, dt_own], dtype=torch.float64, device=collective_device(dev))
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        dt = max(float(v[0].item()) for v in every)                  # MAX over ranks of barrier-to-barrier time
+        per_rank = [B * args.steps / float(v[1].item()) for v in every]
     assert torch.isfinite(x).all()
     value = world * B * args.steps / dt
     # the other way of running the same steps (see above): a short second measurement, outside the timed region
@@ -152,17 +162,20 @@ def main() -> None:
         dom = max(fams, key=lambda f: f["ms"])
         tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         flops_fwd, bytes_fwd = nat.algorithmic_work(B, S, S)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see
-        # tools/pmc_traffic.py); only valid for the workload it was collected on
-        traffic = None
-        pmc = REPO / "profiles" / "r01_pmc_traffic.json"
+        # HBM bytes per launch: a STORED figure from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE
+        # in separate passes, tools/pmc_traffic.py) -- counters cannot be read from inside this process; only quoted for the
+        # workload and library build it was collected on (the file names the library version), else null
+        traffic = traffic_source = None
+        pmc = REPO / "profiles" / PMC_TRAFFIC_FILE
         if pmc.exists() and args.dtype == "bf16" and (B, S, args.base, ch_mult) == (8, 256, 128, (1, 2, 2)):
             pj = json.loads(pmc.read_text())
-            if pj.get("kernel_family") == dom["name"]:
+            same_build = pj.get("library_version") in (None, _native.load_library().ccn_version().decode())
+            if pj.get("kernel_family") == dom["name"] and same_build:
                 traffic = round(pj["hbm_bytes_per_launch"])
+                traffic_source = f"stored: profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc passes of this workload, not this run)"
         roofline = {
             "bound": "mfma", "kernel": dom["name"], "achieved": round(tfs, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-            "frac": round(tfs / PEAK[args.dtype], 4), "traffic": traffic,
+            "frac": round(tfs / PEAK[args.dtype], 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
             "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
             "algorithmic_gflop_per_launch": round(dom["flops"] / dom["calls"] / 1e9, 3),
@@ -174,6 +187,53 @@ def main() -> None:
                               "hbm_gbs_algorithmic": round(bytes_fwd * T * args.steps / dt / 1e9, 1),
                               "hbm_frac": round(bytes_fwd * T * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
         }
+
+    # ---- parity of the timed mode, outside the timed region (rank 0): the bench batch itself, 50 steps, against
+    # (a) the reference's device='cpu' run of record 0 (tests/golden/c2_sample.npz, made by tests/golden/make_golden.py),
+    # (b) this library's fp32 parity mode on all rows, (c) PSNR against synthetic originals in both modes (north_star: 0.1 %)
+    parity = parity_mode = None
+    headline = (S, args.base, ch_mult, T) == (256, 128, (1, 2, 2), 50)
+    if rank == 0 and not args.no_parity:
+        from clip_feature_codec.eval.metrics import psnr
+        x16 = sampler.sample(net, z, (B, 3, S, S), steps=T, x_T=x_T) if args.dtype == "bf16" else None
+        net32 = CLIPCondUNet(512, args.base, ch_mult, dtype="fp32").to(dev).eval()
+        net32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        x32 = sampler.sample(net32, z, (B, 3, S, S), steps=T, x_T=x_T)            # plan + capture
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        x32 = sampler.sample(net32, z, (B, 3, S, S), steps=T, x_T=x_T)
+        torch.cuda.synchronize()
+        p_dt = time.perf_counter() - p0
+        flops32, _ = net32.native().algorithmic_work(B, S, S)
+        parity_mode = {"dtype": "fp32", "value": round(B / p_dt, 3), "unit": "images/sec", "ms_per_step": round(p_dt * 1e3, 2),
+                       "tflops_whole_forward": round(flops32 * T / p_dt / 1e12, 2),
+                       "frac": round(flops32 * T / p_dt / 1e12 / PEAK["fp32"], 4),
+                       "note": "the mode that meets the 1e-3 max-abs gate; one timed step of the same batch, whole forward against the fp32 MFMA peak"}
+        parity = {"workload": "the timed batch: rank 0's records, all DDIM steps"}
+        gold = REPO / "tests" / "golden" / "c2_sample.npz"
+        if headline and gold.exists():
+            g = np.load(gold, allow_pickle=False)["x_final.sub"]                  # 1/16 strided sample of the reference's x_final
+            d32 = np.abs(x32[0, :, ::4, ::4].cpu().numpy() - g)
+            parity["fp32_mode_row0_vs_reference_cpu"] = {"max_abs": float(d32.max()), "mean_abs": float(d32.mean()), "gate_max_abs": 1e-3,
+                                                         "pass": bool(d32.max() < 1e-3)}
+            if x16 is not None:
+                d16 = np.abs(x16[0, :, ::4, ::4].cpu().numpy() - g)
+                parity["bf16_row0_vs_reference_cpu"] = {"max_abs": float(d16.max()), "mean_abs": float(d16.mean())}
+        if x16 is not None:
+            d = (x16 - x32).abs()
+            parity["bf16_vs_fp32_mode_all_rows"] = {"max_abs": float(d.max()), "mean_abs": float(d.mean()),
+                                                    "per_row_mean_abs": [round(float(v), 5) for v in d.mean((1, 2, 3))]}
+            orig = [synth.synth_image(i, S).astype(np.float32).transpose(2, 0, 1) / 127.5 - 1.0 for i in idx]
+            r16, r32 = x16.clamp(-1, 1).cpu().numpy(), x32.clamp(-1, 1).cpu().numpy()
+            p16 = [psnr(orig[k], r16[k]) for k in range(B)]
+            p32 = [psnr(orig[k], r32[k]) for k in range(B)]
+            rel = [abs(a - b) / abs(b) for a, b in zip(p16, p32)]
+            parity["psnr_vs_synthetic_originals"] = {
+                "records": B, "psnr_fp32_mode_mean_db": round(float(np.mean(p32)), 4), "psnr_bf16_mean_db": round(float(np.mean(p16)), 4),
+                "max_rel_delta": float(max(rel)), "mean_rel_delta": float(np.mean(rel)),
+                "rel_delta_of_means": float(abs(np.mean(p16) - np.mean(p32)) / abs(np.mean(p32))),
+                "gate_rel": 1e-3, "pass": bool(max(rel) <= 1e-3)}
+        del net32, x32
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -216,7 +276,9 @@ def main() -> None:
                        "graph": "hipGraph, one replay per step",
                        "steps_in_flight": nfl,
                        ("value_with_two_steps_in_flight" if nfl == 1 else "value_with_one_step_in_flight"): other_value},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "rccl_ranks": ranks_seen, "backend": (dist.get_backend() if world > 1 else None),
+            "per_rank_images_per_sec": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)},
+            "roofline": roofline, "parity": parity, "parity_mode": parity_mode, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -44,6 +44,10 @@ def main() -> None:
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves (child processes, before this process touches the GPU)
+    from clip_feature_codec.utils.launch import ensure_ranks, init_process_group, rank_env
+    ensure_ranks(args.gpus, str(Path(__file__).resolve()))
+
     import torch.distributed as dist
     from clip_feature_codec import _native
     from clip_feature_codec.utils import synth
@@ -51,22 +55,21 @@ def main() -> None:
     from clip_feature_codec.diffusion.scheduler import NoiseScheduler
     from clip_feature_codec.train.diffusion_train import FusedAdamW, train_step
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank, world, local = rank_env()
+    assert world == args.gpus, (world, args.gpus)                    # ensure_ranks guarantees it
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs an MI355X; the HIP path has no CPU fallback")
     dev = f"cuda:{local % torch.cuda.device_count()}"
     torch.cuda.set_device(dev)
+    ranks_seen = 1
     if world > 1:
         # RCCL ("nccl") on a GPU node; CCN_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on one card
-        backend = os.environ.get("CCN_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend)
+        init_process_group(dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} ranks")
     _native.load_library()
 
     ch_mult = tuple(int(v) for v in args.ch_mult.split(","))
@@ -168,6 +171,7 @@ def main() -> None:
                                    "weights, synthetic x0 / z, t and noise drawn per step",
                        "global_batch": world * B,
                        "parallelism": f"dp{world}" + (" (one all-reduce of the flat fp32 gradient buffer per step, RCCL)" if world > 1 else "")},
+            "rccl_ranks": ranks_seen, "backend": (dist.get_backend() if world > 1 else None),
             "final_loss": round(float(loss), 5), "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -291,6 +291,7 @@ class NativeTrainer:
         n, total = c_i32(), c_i64()
         check(self.lib.ccn_train_num_params(self.h, ctypes.byref(n), ctypes.byref(total)))
         self.total = int(total.value)
+        self.serial = 0                       # forwards run so far: the workspace holds the activations of forward number `serial`
         self.layout: List[Tuple[str, Tuple[int, ...], int]] = []
         for i in range(n.value):
             name, shape, nd, off = ctypes.c_char_p(), (c_i64 * 4)(), c_i32(), c_i64()
@@ -331,6 +332,7 @@ class NativeTrainer:
         ws = self.workspace(B, H, W)
         if out is None:
             out = torch.empty_like(x)
+        self.serial += 1
         with torch.cuda.device(x.device):
             check(self.lib.ccn_train_forward(self.h, flat.data_ptr(), x.data_ptr(), z.data_ptr(), t.data_ptr(), out.data_ptr(),
                                              B, H, W, ws.ptr, ws.nbytes, current_stream(x.device)))

@@ -61,7 +61,8 @@ def gather_metric_rows(local_idx: Sequence[int], local_rows: np.ndarray, n_total
     for k, (i, row) in enumerate(zip(local_idx, local_rows)):
         block[k, 0] = i
         block[k, 1:] = torch.as_tensor(row, dtype=torch.float64)
-    block = block.to(device)
+    from ..utils.launch import collective_device
+    block = block.to(collective_device(device))
     blocks = [torch.empty_like(block) for _ in range(world)]
     dist.all_gather(blocks, block)
     for blk in blocks:
@@ -127,16 +128,23 @@ def main(argv=None) -> None:
     ap.add_argument("--batch", type=int, default=8, help="records per fused DDIM launch per GPU")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="shard the store over this many GPUs of the node: one process per GPU is started here unless a launcher "
+                         "(torchrun) already did; default: the launcher's WORLD_SIZE, else 1")
     args = ap.parse_args(argv)
+
+    from ..utils.launch import ensure_ranks, init_process_group, rank_env
+    if args.gpus is not None:
+        # starts the ranks (fresh child processes) and exits with their code unless this process already is one of them
+        ensure_ranks(args.gpus, "clip_feature_codec.cli.eval", argv, module=True)
 
     from ._common import pick_device, load_codec_meta, load_embedding, build_model, build_sampler, start_noise
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    rank, world, _ = rank_env()
     device = pick_device(args.device)
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    if world > 1:
+        init_process_group(device)                                 # RCCL; CCN_DIST_BACKEND=gloo for several ranks on one card
 
     store_dir = Path(args.store_dir)
     manifest = json.loads((store_dir / "manifest.json").read_text(encoding="utf-8"))

@@ -113,7 +113,11 @@ class CLIPCondUNet(nn.Module):
                 "call .to('cuda') or run the reference package for device='cpu'")
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        key = (str(dev), self.compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        # parameters re-homed into the trainer's flat buffer are written by the fused AdamW kernel through that buffer: its version
+        # counter (bumped by FusedAdamW.step) is part of the key, the views' own counters do not move
+        st = getattr(self, "_train_state", None)
+        flat_version = st.fp.flat._version if st is not None and st.fp.intact() else None
+        key = (str(dev), self.compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params), flat_version)
         if self._nat is None or self._nat_key != key:
             if self._nat is not None:
                 self._nat.close()

@@ -57,6 +57,16 @@ class FlatParams:
     def params(self) -> List[nn.Parameter]:
         return [p for p, _, _ in self.views]
 
+    def grads_bound(self) -> Optional[str]:
+        """'views' if every ``p.grad`` is its view of the flat gradient buffer, 'none' if every one is None, else None (foreign)."""
+        base = self.grad.data_ptr()
+        n_none = sum(1 for p, _, _ in self.views if p.grad is None)
+        if n_none == len(self.views):
+            return "none"
+        if n_none == 0 and all(p.grad.data_ptr() == base + 4 * off for p, off, _ in self.views):
+            return "views"
+        return None
+
     def rebind_grads(self) -> None:
         """Make every ``p.grad`` a view of the flat gradient buffer again (after ``zero_grad(set_to_none=True)``)."""
         for p, off, n in self.views:
@@ -65,7 +75,14 @@ class FlatParams:
 
 
 class UNetFunction(torch.autograd.Function):
-    """eps_hat = UNet(x_t, z, t) with the library's backward.  Inputs after ``t`` are the parameters (autograd leaves)."""
+    """eps_hat = UNet(x_t, z, t) with the library's backward.  Inputs after ``t`` are the parameters (autograd leaves).
+
+    The trainer keeps the activations of ONE forward (its workspace), so every forward takes a serial number and a backward whose
+    serial is no longer the trainer's latest raises instead of differentiating the wrong activations (two forwards before one
+    backward: micro-batches, teacher/student double calls).  When every ``p.grad`` is the parameter's view of the flat gradient
+    buffer (or None), the library accumulates straight into that buffer and the node returns no parameter gradients -- no
+    per-step 130 MB scratch, no second accumulation pass by autograd; otherwise (foreign ``p.grad`` tensors) it falls back to a
+    scratch buffer that autograd accumulates."""
 
     @staticmethod
     def forward(ctx, state, x_t, z, t, *params):
@@ -74,6 +91,7 @@ class UNetFunction(torch.autograd.Function):
         ctx.state = state
         ctx.save_for_backward(x, zz)
         ctx.version = state.fp.flat._version
+        ctx.serial = state.trainer.serial
         return eps
 
     @staticmethod
@@ -82,9 +100,25 @@ class UNetFunction(torch.autograd.Function):
         x, zz = ctx.saved_tensors
         if state.fp.flat._version != ctx.version:
             raise RuntimeError("parameters were modified between the training forward and its backward")
-        g = torch.zeros_like(state.fp.flat)
-        state.trainer.backward(state.fp.flat, g, x, zz, _native.require_dev(d_eps, "d_eps"))
-        grads = tuple(g[off:off + n].view(p.shape) for p, off, n in state.fp.views)
+        if state.trainer.serial != ctx.serial:
+            raise RuntimeError("another training forward of this model ran before this backward: the library keeps the activations "
+                               "of one forward at a time (run forward -> backward pairs, e.g. one micro-batch after the other)")
+        fp = state.fp
+        d = _native.require_dev(d_eps, "d_eps")
+        mode = fp.grads_bound()
+        if mode is not None:
+            if mode == "none":                     # after zero_grad(set_to_none=True): the buffer holds stale sums
+                fp.grad.zero_()
+            fp.rebind_grads()
+            if state.ddp_bucketed and state.world() > 1:
+                d = d * (1.0 / state.world())      # the sum over ranks is then already the mean
+                state.trainer.backward(fp.flat, fp.grad, x, zz, d, bucket_cb=state.enqueue_bucket)
+            else:
+                state.trainer.backward(fp.flat, fp.grad, x, zz, d)
+            return (None,) * (4 + len(fp.views))
+        g = torch.zeros_like(fp.flat)
+        state.trainer.backward(fp.flat, g, x, zz, d)
+        grads = tuple(g[off:off + n].view(p.shape) for p, off, n in fp.views)
         return (None, None, None, None) + grads
 
 
@@ -97,6 +131,23 @@ class TrainState:
                                              dtype=dtype, device=device)
         self.fp = FlatParams(net, self.trainer)
         self.dtype = dtype
+        self.ddp_bucketed = False          # UNetFunction.backward all-reduces finished gradient ranges while it still runs
+        self._works: list = []
+
+    @staticmethod
+    def world() -> int:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def enqueue_bucket(self, lo: int, hi: int) -> None:
+        import torch.distributed as dist
+        self._works.append(dist.all_reduce(self.fp.grad[lo:hi], async_op=True))
+
+    def wait_grad_sync(self) -> None:
+        """Join the bucket all-reduces the last backward enqueued (call before the optimiser step)."""
+        for w in self._works:
+            w.wait()
+        self._works.clear()
 
     def apply(self, x_t, z, t):
         return UNetFunction.apply(self, x_t, z, t, *self.fp.params())
@@ -257,6 +308,8 @@ def train_diffusion(store_dir, out_size: int = 256, epochs: int = 40, batch_size
     sch = NoiseScheduler(timesteps=timesteps, schedule=schedule, device=device)
     net.train()
     state = net.train_state(device)
+    # data parallel: finished ranges of the flat gradient buffer are all-reduced (RCCL) while the backward still runs
+    state.ddp_bucketed = ddp
     opt = FusedAdamW(net, lr=lr)
     if clip_w > 0:
         try:
@@ -288,8 +341,7 @@ def train_diffusion(store_dir, out_size: int = 256, epochs: int = 40, batch_size
                 if tv_w > 0:
                     loss = loss + tv_w * total_variation(x0_pred)
             loss.backward()
-            if ddp:
-                average_gradients(state.fp.grad)
+            state.wait_grad_sync()
             opt.step()
             opt.zero_grad()
             running += float(loss.detach()) * b

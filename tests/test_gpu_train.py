@@ -357,3 +357,105 @@ def test_two_rank_training_with_overlapped_allreduce_equals_single_process(tmp_p
     init = np.concatenate([v.reshape(-1) for v in synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2))).values()])
     moved = np.abs(p1 - init).max()
     assert moved > 0 and np.abs(p1 - p2).max() <= 0.05 * moved
+
+
+# ---- round-2 additions: advisor findings on the drop-in route ---------------------------------------------------------------
+def test_eval_between_fused_adamw_steps_uses_the_current_weights():
+    """FusedAdamW writes the parameters through the flat buffer (the views' own version counters do not move): an eval forward /
+    preview sample between training steps must still see the updated weights -- each compared with the oracle on the CURRENT
+    state_dict."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    sch = NoiseScheduler(1000, "cosine", device=DEV)
+    opt = FusedAdamW(net, lr=5e-3)
+    g = torch.Generator("cpu").manual_seed(21)
+    x0 = torch.rand((2, 3, 32, 32), generator=g) * 2 - 1; z = torch.from_numpy(synth.synth_z(2))
+    xe = torch.randn((2, 3, 32, 32), generator=g); te = torch.tensor([700, 20])
+
+    def eval_err():
+        net.eval()
+        with torch.no_grad():
+            got = net(xe.to(DEV), z.to(DEV), te.to(DEV)).cpu()
+            ref = ref_unet.unet_forward({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, xe, z, te)
+        net.train()
+        return got, float((got - ref).abs().max())
+
+    e0, err0 = eval_err()
+    assert err0 < 2e-5, err0
+    train_step(net, sch, opt, x0.to(DEV), z.to(DEV))
+    e1, err1 = eval_err()                                      # handle built BEFORE this step must not be reused
+    assert err1 < 2e-5, err1
+    assert float((e1 - e0).abs().max()) > 1e-4                 # the step really moved the output
+    for _ in range(2):
+        train_step(net, sch, opt, x0.to(DEV), z.to(DEV))
+    e2, err2 = eval_err()
+    assert err2 < 2e-5 and float((e2 - e1).abs().max()) > 1e-4, (err2,)
+
+
+def test_two_training_forwards_before_a_backward_raise():
+    """The trainer holds one forward's activations: a backward of an older forward must raise, not differentiate the newer one."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    g = torch.Generator("cpu").manual_seed(22)
+    xa, xb = (torch.randn((1, 3, 32, 32), generator=g).to(DEV) for _ in range(2))
+    z = torch.from_numpy(synth.synth_z(1)).to(DEV); t = torch.tensor([300], device=DEV)
+    la = net(xa, z, t).square().mean()
+    lb = net(xb, z, t).square().mean()
+    with pytest.raises(RuntimeError, match="another training forward"):
+        (la + lb).backward()
+    # forward -> backward pairs (micro-batches) work and accumulate in the flat gradient buffer
+    net.zero_grad(set_to_none=True)
+    net(xa, z, t).square().mean().backward()
+    ga = net.train_state().fp.grad.clone()
+    net(xb, z, t).square().mean().backward()
+    gab = net.train_state().fp.grad.clone()
+    net.zero_grad(set_to_none=True)
+    net(xb, z, t).square().mean().backward()
+    gb = net.train_state().fp.grad.clone()
+    scale = float(gab.abs().max())
+    assert float((gab - (ga + gb)).abs().max()) <= 1e-5 * scale
+    p = next(net.parameters())
+    assert p.grad.data_ptr() == net.train_state().fp.grad.data_ptr() + 4 * net.train_state().fp.views[0][1]
+
+
+def _ddp_grad_rank(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2))
+    st = net.train_state()
+    x, z, t, noise = (torch.from_numpy(GOLD[k]) for k in ("x_t", "z", "t", "noise"))
+    B = x.shape[0]
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    x, z, t, noise = (v[lo:hi].to(DEV) for v in (x, z, t, noise))
+    eps = st.trainer.forward(st.fp.flat, x, z, t)
+    _, d = _native.mse_loss_grad(eps, noise)
+    d.mul_(1.0 / world)
+    st.fp.grad.zero_()
+    works = []
+    st.trainer.backward(st.fp.flat, st.fp.grad, x, z, d, bucket_floats=200_000,
+                        bucket_cb=(lambda a, b: works.append(dist.all_reduce(st.fp.grad[a:b], async_op=True))) if world > 1 else None)
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(out, st.fp.grad.cpu().numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_allreduce_gives_the_full_batch_gradient(tmp_path):
+    """One bucketed backward per rank on half of the fixture's batch, every bucket all-reduced as it is handed out: the reduced flat
+    gradient equals the single-process full-batch gradient to 1e-5 of its max (catches a wrong 1/world scale or a missed bucket,
+    which parameter positions after Adam steps cannot).  gloo on one card: the RCCL stream-ordering of the callback is exercised
+    only on a multi-GPU node (bench_train.py --gpus N)."""
+    import torch.multiprocessing as mp
+    _ddp_grad_rank(0, 1, 0, str(tmp_path / "g1.npy"))
+    mp.spawn(_ddp_grad_rank, args=(2, 29573, str(tmp_path / "g2.npy")), nprocs=2, join=True)
+    g1, g2 = np.load(tmp_path / "g1.npy"), np.load(tmp_path / "g2.npy")
+    assert np.abs(g1).max() > 0
+    assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max(), np.abs(g1 - g2).max() / np.abs(g1).max()
