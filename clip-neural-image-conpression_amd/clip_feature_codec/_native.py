@@ -45,6 +45,7 @@ SIGNATURES = {
     "ccn_resblock_forward": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_timestep_embedding": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "ccn_read_activation": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_sz, c_vp]),
+    "ccn_poll_errors": (c_i32, [c_vp]),
     "ccn_profile_enable": (c_i32, [c_vp, c_i32]),
     "ccn_profile_read": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f32), ctypes.POINTER(c_i32),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
@@ -141,6 +142,8 @@ class Workspace:
 class NativeUNet:
     """One ccn_handle_t: repacked weights + cached plans/graphs for a CLIPCondUNet."""
 
+    MAX_WORKSPACES = 8
+
     def __init__(self, z_dim: int, base: int, ch_mult: Sequence[int], time_dim: int, img_ch: int,
                  groups: int = 8, dtype="fp32", device="cuda") -> None:
         self.lib = load_library()
@@ -195,12 +198,17 @@ class NativeUNet:
     def workspace(self, B: int, H: int, W: int, steps: int, slot: int = 0) -> Workspace:
         """``slot``: independent scratch (and, inside the library, plan + captured graph) for callers that keep several batches in flight."""
         key = (B, H, W, steps, slot)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None:
+            # as many live workspaces as the library caches plans (8): the least recently used one goes back to torch's
+            # allocator, after draining the device -- a replay on a side stream may still be writing it
+            while len(self._ws) >= self.MAX_WORKSPACES:
+                torch.cuda.synchronize(self.device)
+                self._ws.pop(next(iter(self._ws)))
             n = c_sz()
             check(self.lib.ccn_workspace_bytes(self.h, B, H, W, steps, ctypes.byref(n)))
             ws = Workspace(n.value, self.device)
-            self._ws[key] = ws
+        self._ws[key] = ws                        # (re)insert as most recently used
         return ws
 
     # -- hot path ----------------------------------------------------------------------------
@@ -252,6 +260,10 @@ class NativeUNet:
         with torch.cuda.device(self.device):
             check(self.lib.ccn_read_activation(self.h, name.encode(), out.data_ptr(), out.numel(), current_stream(self.device)))
         return out
+
+    def poll_errors(self) -> None:
+        """Raise if a kernel reported a device-side failure since the last check (call after synchronising the stream)."""
+        check(self.lib.ccn_poll_errors(self.h))
 
     def profile(self, on: bool) -> None:
         check(self.lib.ccn_profile_enable(self.h, 1 if on else 0))

@@ -128,7 +128,7 @@ struct Plan {
     std::vector<std::pair<void*, size_t>> zero_once;   // regions zeroed when the plan is created (split-K hand-off flags)
     unsigned* counters = nullptr;        // arrival counters of the fused GroupNorm finalizes, [kMaxNorms][B], zero at rest
     int n_counters = 0;
-    std::vector<int32_t> ts_keep;        // host copy of the last timestep table (source of the async upload)
+    std::vector<int32_t> ts_keep;        // the timestep table currently in ts_dev (uploaded synchronously, only when it changes)
     std::vector<Launch> ops;             // one UNet evaluation (+ DDIM update in the head)
     std::map<std::string, TensorRef> named;
     std::vector<GraphEntry> graphs;
@@ -162,6 +162,8 @@ struct ccn_handle_s {
     int G = 8;
     std::vector<std::unique_ptr<Plan>> plans;
     hipStream_t cap_stream = nullptr;
+    unsigned* err_host = nullptr;       // pinned, device-mapped error word the kernels OR into (ConvArgs::err)
+    unsigned* err_dev = nullptr;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -437,13 +439,13 @@ struct PlanBuilder {
     // 2 when the layer should run split-K on the persistent kernel (see conv()), else 1
     int split_k_for(const ConvW& cw, const ConvGeom& g, bool has_gn, bool s2pr) const
     {
-        static const bool off = getenv("CCN_NO_SPLITK") != nullptr;
+        static const bool off = diag_env("CCN_NO_SPLITK") != nullptr;
         if (off || h->cfg.dtype != CCN_DTYPE_BF16 || !cw.wfrag || cw.BN != 128) return 1;
         // Measured at C2: a single-tile-per-workgroup launch of the persistent kernel carries ~25 us of fixed cost (cold first
         // chunk, serial last epilogue, hand-off), so halving the K loop of the 32-pixel 3x3 s1 layers (56 us) does not beat the
         // 4-row kernel (53 us); it does help the stride-2 conv into that level (63 -> 56 us), whose alternative is 128 tiles.
         // CCN_SPLITK_S1=1 enables it for the stride-1 layers too.
-        static const bool s1_too = getenv("CCN_SPLITK_S1") != nullptr;
+        static const bool s1_too = diag_env("CCN_SPLITK_S1") != nullptr;
         if (!((cw.kind == KIND_C3S1 && s1_too) || (cw.kind == KIND_C3S2 && s2pr))) return 1;
         if (!conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, 8)) return 1;
         const int cke = 64;
@@ -501,6 +503,7 @@ struct PlanBuilder {
         a.use_stem2 = stem2 ? 1 : 0;
         if (stem2) { a.wfrag = cw.wfrag; a.nslot = 4 * stem2_blocks(in.H, in.W, nullptr); }   // one slot per wave
         a.film_bstride = film_stride;
+        a.err = h->err_dev;
         fill_taps(a, cw.kind);
         if (want_part) {
             out.part = (float2*)bump.take((size_t)B * a.G * a.nslot * sizeof(float2));
@@ -543,7 +546,7 @@ struct PlanBuilder {
         const double count = (double)cpg * t.H * t.W;
         // measured slower than the 5 us finalize launch it removes (every workgroup drains its stores and pays an atomic
         // round trip before exiting): 50.4 vs 52.1 img/s at C2, so opt-in only
-        static const bool fuse = getenv("CCN_FUSED_FINALIZE") != nullptr;
+        static const bool fuse = diag_env("CCN_FUSED_FINALIZE") != nullptr;
         if (fuse && t.prod && !t.pr && plan->counters && plan->n_counters < kMaxNorms) {
             // the producing conv's last workgroup per sample does the finalize (no launch, no kernel boundary)
             ConvArgs& pa = *t.prod;
@@ -607,10 +610,10 @@ struct PlanBuilder {
     {
         // pre-pass only where the conv kernel would redo the transform per N tile AND has no idle VALU for it: the persistent
         // kernel's producers absorb it (CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
-        static const bool preact_pr = getenv("CCN_PREACT_PR") != nullptr;
+        static const bool preact_pr = diag_env("CCN_PREACT_PR") != nullptr;
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
                          (preact_pr || r.c1.Cout_pad / r.c1.BN >= 4 || !will_use_pr(r.c1, x.H, x.W));
-        static const bool fuse_act = !getenv("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
+        static const bool fuse_act = !diag_env("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
         const bool f1 = pre && fuse_act && x.n_sp > 0, f2 = pre && fuse_act;     // (n_sp, not the pointer: null while measuring)
         TensorRef y = new_tensor(r.C, x.H, x.W);
         if (f1) { TensorRef xa = preact_fused(x, r.n1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
@@ -689,7 +692,7 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
                 break;
             }
             case L_HEAD: {
-                static const bool no_head2 = getenv("CCN_NO_HEAD2") != nullptr;
+                static const bool no_head2 = diag_env("CCN_NO_HEAD2") != nullptr;
                 if (!no_head2 && head2_supported(c.dtype, h->head.Cin, h->head.Cout, h->G)) {
                     // dedicated kernel pair: out_norm's finalize folded into per-sample head weights, taps in the N dimension
                     std::shared_ptr<ConvArgs> ap(new ConvArgs());
@@ -721,6 +724,16 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
     return CCN_OK;
 }
 
+// A Plan owns hipGraphExec objects whose replays may still be running on caller streams (two batches in flight in cli.eval /
+// bench.py): drain the device before destroying any of them.
+void drop_plans(ccn_handle_s* h, size_t keep_newest)
+{
+    if (h->plans.size() <= keep_newest) return;
+    (void)hipDeviceSynchronize();
+    while (h->plans.size() > keep_newest) h->plans.erase(h->plans.begin());
+}
+
+
 int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t ws_bytes, Plan** out)
 {
     if (B <= 0 || H <= 0 || W <= 0 || steps <= 0) return fail(CCN_EINVAL, "B, H, W, steps must be positive");
@@ -740,7 +753,7 @@ int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t w
     if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(p->bytes));
     HIPCHK(hipMemset(p->counters, 0, (size_t)kMaxNorms * B * 4));          // arrival counters start (and are left) at zero
     for (auto& z : p->zero_once) HIPCHK(hipMemset(z.first, 0, z.second));
-    if (h->plans.size() >= 8) h->plans.erase(h->plans.begin());
+    if (h->plans.size() >= 8) drop_plans(h, 7);
     *out = p.get();
     h->plans.push_back(std::move(p));
     return CCN_OK;
@@ -807,11 +820,23 @@ int run_steps(ccn_handle_s* h, Plan* p, hipStream_t s, int steps, const float* c
     return CCN_OK;
 }
 
+// sticky device-side failure (a kernel ORed into the error word since the last check): report once, then clear
+int check_device_errors(ccn_handle_s* h)
+{
+    if (!h->err_host) return CCN_OK;
+    const unsigned e = __atomic_exchange_n(h->err_host, 0u, __ATOMIC_RELAXED);
+    if (e & 1u)
+        return fail(CCN_EHIP, "device-side hand-off timeout: a split-K partial tile never arrived; the results of the launches enqueued "
+                              "since the last successful check are invalid");
+    if (e) return fail(CCN_EHIP, "device-side error word " + std::to_string(e));
+    return CCN_OK;
+}
+
 int check_ready(ccn_handle_s* h)
 {
     if (!h) return fail(CCN_EINVAL, "null handle");
     if (!h->committed) return fail(CCN_ESTATE, "ccn_commit_params has not succeeded on this handle");
-    return CCN_OK;
+    return check_device_errors(h);
 }
 
 }  // namespace
@@ -820,7 +845,11 @@ int check_ready(ccn_handle_s* h)
 extern "C" {
 
 const char* ccn_last_error(void) { return g_err.c_str(); }
-const char* ccn_version(void) { return "ccn_hip 0.1 (gfx950)"; }
+#ifdef CCN_DIAG
+const char* ccn_version(void) { return "ccn_hip 0.2 (gfx950, diagnostics build)"; }
+#else
+const char* ccn_version(void) { return "ccn_hip 0.2 (gfx950)"; }
+#endif
 
 int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out)
 {
@@ -847,6 +876,9 @@ int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out)
         if (r.C % (r.C < h->G ? r.C : h->G)) return fail(CCN_EINVAL, "channel count not divisible by GroupNorm groups");
     HIPCHK(conv_prepare());
     HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped));
+    *h->err_host = 0u;
+    HIPCHK(hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0));
     for (int i = 0; i < F_COUNT; ++i) h->fam_names.push_back(kFamilies[i]);
     *out = h.release();
     return CCN_OK;
@@ -860,6 +892,7 @@ int ccn_destroy(ccn_handle_t h)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;
     return CCN_OK;
 }
@@ -912,7 +945,7 @@ int ccn_commit_params(ccn_handle_t h)
     for (auto& p : h->params)
         if (!h->host.count(p.name)) missing += (missing.empty() ? "" : ", ") + p.name;
     if (!missing.empty()) return fail(CCN_EWEIGHTS, "Missing key(s) in state_dict: " + missing);
-    h->plans.clear();
+    drop_plans(h, 0);                                             // drains the device first: replays may still read the old weights
     for (void* p : h->dev_allocs) (void)hipFree(p);
     h->dev_allocs.clear();
     const ccn_config_t& c = h->cfg;
@@ -1011,8 +1044,13 @@ int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* 
     HIPCHK(hipMemcpyAsync(p->zbuf, z_dev, (size_t)B * h->cfg.z_dim * 4, hipMemcpyDeviceToDevice, s));
     if (x_T_dev != p->xstate) HIPCHK(hipMemcpyAsync(p->xstate, x_T_dev, img_bytes, hipMemcpyDeviceToDevice, s));
 
-    p->ts_keep.assign(ts_host, ts_host + steps);
-    HIPCHK(hipMemcpyAsync(p->ts_dev, p->ts_keep.data(), (size_t)steps * 4, hipMemcpyHostToDevice, s));
+    // the timestep table of a plan almost never changes: upload it only when it does, and then synchronously after draining
+    // the stream (an async copy out of a host vector that the next call rewrites could still be pending)
+    if (p->ts_keep.size() != (size_t)steps || std::memcmp(p->ts_keep.data(), ts_host, (size_t)steps * 4)) {
+        HIPCHK(hipStreamSynchronize(s));
+        p->ts_keep.assign(ts_host, ts_host + steps);
+        HIPCHK(hipMemcpy(p->ts_dev, p->ts_keep.data(), (size_t)steps * 4, hipMemcpyHostToDevice));
+    }
     if (use_graph && !h->profiling) {
         GraphEntry* ge = nullptr;
         for (auto& g : p->graphs)
@@ -1100,20 +1138,26 @@ int ccn_resblock_forward(ccn_handle_t h, const char* prefix, const float* x_dev,
     if (!r) return fail(CCN_EINVAL, std::string("no ResBlock with prefix ") + prefix);
     if ((uintptr_t)workspace_dev & 255) return fail(CCN_EWORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    Plan tmp; tmp.B = B; tmp.H = H; tmp.W = W; tmp.steps = 1;
-    PlanBuilder pb(h, &tmp, workspace_dev, false);
-    pb.film_stride = 2 * r->C;                                    // dense (B, 2C) table: [scale | shift] of this block only
-    tmp.film = (float*)pb.bump.take((size_t)B * 2 * r->C * 4);
-    tmp.counters = (unsigned*)pb.bump.take((size_t)8 * B * 4);
-    tmp.n_counters = 0;
-    HIPCHK(hipMemsetAsync(tmp.counters, 0, (size_t)8 * B * 4, s));
-    TensorRef x = pb.new_tensor(r->C, H, W);
-    const int G = pb.groups_for(r->C), cpg = r->C / G;
+    const int G = (r->C < h->G ? r->C : h->G), cpg = r->C / G;
     int nslot = (H * W + 1023) / 1024; if (nslot < 1) nslot = 1;
-    x.part = (float2*)pb.bump.take((size_t)B * G * nslot * sizeof(float2));
-    x.n_sp = nslot; x.n_nt = 1; x.bn = 1 << 30;
-    TensorRef o = pb.resblock(*r, x, false, 0);
-    if (pb.bump.off > workspace_bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(pb.bump.off));
+    Plan tmp; tmp.B = B; tmp.H = H; tmp.W = W; tmp.steps = 1;
+    TensorRef x, o;
+    // pass 0 measures (nothing is written before the size is known to fit), pass 1 places the buffers
+    for (int pass = 0; pass < 2; ++pass) {
+        tmp.ops.clear(); tmp.named.clear(); tmp.zero_once.clear();
+        PlanBuilder pb(h, &tmp, workspace_dev, pass == 0);
+        pb.film_stride = 2 * r->C;                                // dense (B, 2C) table: [scale | shift] of this block only
+        tmp.film = (float*)pb.bump.take((size_t)B * 2 * r->C * 4);
+        tmp.counters = (unsigned*)pb.bump.take((size_t)8 * B * 4);
+        tmp.n_counters = 0;
+        x = pb.new_tensor(r->C, H, W);
+        x.part = (float2*)pb.bump.take((size_t)B * G * nslot * sizeof(float2));
+        x.n_sp = nslot; x.n_nt = 1; x.bn = 1 << 30;
+        o = pb.resblock(*r, x, false, 0);
+        if (pb.bump.off > workspace_bytes) return fail(CCN_EWORKSPACE, "workspace too small: need " + std::to_string(pb.bump.off));
+    }
+    HIPCHK(hipMemsetAsync(tmp.counters, 0, (size_t)8 * B * 4, s));
+    for (auto& z : tmp.zero_once) HIPCHK(hipMemsetAsync(z.first, 0, z.second, s));   // split-K hand-off flags of a fresh workspace
     HIPCHK(launch_nchw_to_nhwc(h->cfg.dtype, x_dev, x.p, B, r->C, H, W, s));
     HIPCHK(launch_gn_partials(h->cfg.dtype, x.p, x.part, B, H * W, r->C, cpg, G, nslot, s));
     HIPCHK(launch_linear(cond_dev, nullptr, 1, B, h->film_w + (size_t)r->film_off * h->cfg.time_dim, h->film_b + r->film_off,
@@ -1139,6 +1183,12 @@ int ccn_read_activation(ccn_handle_t h, const char* name, float* out_dev, size_t
     HIPCHK(launch_nhwc_to_nchw(h->cfg.dtype, t.p, out_dev, p->B, t.C, t.H, t.W, s));
     HIPCHK(hipStreamSynchronize(s));
     return CCN_OK;
+}
+
+int ccn_poll_errors(ccn_handle_t h)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    return check_device_errors(h);
 }
 
 int ccn_profile_enable(ccn_handle_t h, int32_t on)

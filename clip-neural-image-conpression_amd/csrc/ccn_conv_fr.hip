@@ -76,8 +76,8 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
     const bool gn = a.gn_ab != nullptr;
     const int iy0 = my0 - 1, ix0 = mx0 - 1;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == A0)) {
-            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8;
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == A0)) {
+            unsigned long long* st = CCN_STAMPS_PTR(a) + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8;
             st[slot] = __builtin_amdgcn_s_memrealtime();
             if (slot == 1) st[5] = __builtin_amdgcn_s_memtime();
             if (slot == 2) st[6] = __builtin_amdgcn_s_memtime();
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
         asm volatile("" ::: "memory");
     };
     auto loop_barrier = [&]() __attribute__((always_inline)) {
-        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
+        if (CCN_STAMPS_PTR(a)) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
         else raw_barrier();
     };
     auto stamp_wait = [&]() __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == A0))
-            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8 + 4] = bar_wait;
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == A0))
+            CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : 2)) * 8 + 4] = bar_wait;
     };
     stamp(0);
     const size_t wtap_bytes = (size_t)a.Cout_pad * a.Cin_pad * sizeof(T);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
             }
         }
     };
-    const bool do_epi = !(a.dbg & 8);
+    const bool do_epi = !CCN_DBG_BIT(a, 8);
 
     if (wave >= A0) {
         // ------------------------------------------------------------------ A producers (4 waves)
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
         raw_barrier();                                             // chunk 0 visible
         stamp(1);
         for (int chunk = 0; chunk + 1 < a.nchunk; ++chunk) {
-            if (!(a.dbg & 1)) {
+            if (!CCN_DBG_BIT(a, 1)) {
                 const bool cv = (chunk + 1) * CKE + ck * EPC < a.Cin;
                 if (gn && cv) {
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
                 }
             }
             loop_barrier();                                        // consumers are done with chunk `chunk`
-            if (!(a.dbg & 1)) {
+            if (!CCN_DBG_BIT(a, 1)) {
 #pragma unroll
                 for (int i = 0; i < AIT; ++i) {
                     const int px = (ptid >> 3) + NA * 8 * i;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512) void conv_fr_kernel(const ConvArgs a)
                 }
             }
             loop_barrier();                                        // chunk `chunk + 1` visible
-            if (!(a.dbg & 1)) a_req_all(chunk + 2);
+            if (!CCN_DBG_BIT(a, 1)) a_req_all(chunk + 2);
         }
         stamp(2); stamp_wait();
         if (do_epi) {
@@ -481,7 +481,7 @@ extern "C" int ccn_internal_dump_stamps_fr(const char* path)
 hipError_t launch_conv_fr(int dtype, int bn, const ConvArgs& a, hipStream_t s)
 {
     const unsigned grid = (unsigned)(a.B * a.n_ty * a.n_tx * a.npar * a.n_nt);
-    static const char* env = getenv("CCN_STAMPS");
+    static const char* env = diag_env("CCN_STAMPS");
     if (env) {
         unsigned want = (unsigned)atoi(env), want_taps = strchr(env, ':') ? (unsigned)atoi(strchr(env, ':') + 1) : 9u;
         if (grid == want && (unsigned)a.ntaps == want_taps && grid <= 8192) {

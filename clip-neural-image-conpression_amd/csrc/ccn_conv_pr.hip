@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto vt_kh = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v & 1) : 0; };
 
     const unsigned char* const inb = (const unsigned char*)a.in;
-    const bool gn = a.gn_ab != nullptr && !(a.dbg & 32);     // CCN_DBG=32: skip the transform (timing experiments only)
+    const bool gn = a.gn_ab != nullptr && !CCN_DBG_BIT(a, 32);     // CCN_DBG=32: skip the transform (timing experiments only)
     constexpr unsigned OOB = 0x7FFFFFF0u;
     auto raw_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -103,19 +103,19 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         asm volatile("" ::: "memory");
     };
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4))
-            a.stamps[((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == 4))
+            CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
     };
     // diagnostics (CCN_STAMPS): shader-clock cycles spent waiting at barriers / in phases, per role
     unsigned long long t_bar = 0, t_a = 0, t_b = 0, t_w = 0, t_r = 0;
-    const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_begin = CCN_STAMPS_PTR(a) ? __builtin_amdgcn_s_memtime() : 0;
     auto timed_barrier = [&]() __attribute__((always_inline)) {
-        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); t_bar += __builtin_amdgcn_s_memtime() - t0; }
+        if (CCN_STAMPS_PTR(a)) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); t_bar += __builtin_amdgcn_s_memtime() - t0; }
         else raw_barrier();
     };
     auto stamp_cycles = [&]() __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4)) {
-            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8;
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == 4)) {
+            unsigned long long* st = CCN_STAMPS_PTR(a) + ((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8;
             st[3] = t_bar; st[4] = __builtin_amdgcn_s_memtime() - t_begin; st[5] = t_a; st[6] = t_b; st[7] = t_r;
         }
     };
@@ -282,12 +282,17 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 if (lane == 0) {
                     int spins = 0;
                     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                    // the partner never arrived (it cannot happen while both halves are co-resident, which launch_conv_pr
+                    // guarantees): the tile below is then wrong -- say so in the handle's error word, which the next API call
+                    // (or ccn_poll_errors) turns into CCN_EHIP, instead of falling through silently
+                    if (spins >= (1 << 22) && a.err) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
                 }
                 // No agent-scope acquire fence here (it would invalidate the XCD's whole L2): the partner workgroup runs on the
-                // same XCD (adjacent virtual tiles, XCD-contiguous mapping above), its stores are write-through to that L2, and
-                // this CU cannot hold stale lines of the partial tensor (L1 is invalidated at kernel start and the lines are
-                // read for the first time now, with the L1-bypass bit set for good measure).
+                // same XCD -- partners are virtual tiles 2t, 2t+1 and launch_conv_pr makes the split-K grid a multiple of 16, so
+                // that every XCD's contiguous range [x*grid/8, (x+1)*grid/8) starts at an even id and holds whole pairs -- its
+                // stores are write-through to that L2, and this CU cannot hold stale lines of the partial tensor (L1 is
+                // invalidated at kernel start and the lines are read for the first time now, with the L1-bypass bit set).
                 asm volatile("" ::: "memory");
             }
             const int nb = e_nt * BN + o16 * 8;
@@ -404,20 +409,20 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         stamp(1);
         int c = 0, ti = 0;
         for (int k = 0; k < ktotal; ++k) {
-            unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
-            if (a.stamps) {                                        // diagnostic: separate the wait for the chunk registers from the work
+            unsigned long long t0 = CCN_STAMPS_PTR(a) ? __builtin_amdgcn_s_memtime() : 0;
+            if (CCN_STAMPS_PTR(a)) {                                        // diagnostic: separate the wait for the chunk registers from the work
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_w += t1 - t0; t0 = t1;
             }
             if (k + 1 < ktotal) { prep(); dump((k + 1) & 1); }
-            if (a.stamps) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
+            if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
             if (epi) epi_request();
             if (k + 1 < ktotal) issue();
             if (c == nck - 1) epi_setup(vb + ti * grid);           // this tile finishes in this iteration
-            if (a.stamps) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
+            if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
             if (epi) epilogue();
-            if (a.stamps) t_b += __builtin_amdgcn_s_memtime() - t0;
+            if (CCN_STAMPS_PTR(a)) t_b += __builtin_amdgcn_s_memtime() - t0;
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
             if (++c == nck) { c = 0; ++ti; }
         }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     }
 
     // ---------------------------------------------------------------------- consumers (4 waves)
-    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
+    if (!CCN_DBG_BIT(a, 16)) __builtin_amdgcn_s_setprio(2);
     if constexpr (NTAPS == 9 && COLW) {
         // 3x3, column-per-wave form: wave w owns ALL 8 tile rows of the 32 output channels nt*128 + 32w.  Per (dx, k-slice)
         // group it needs 3 weight fragments (one per dy) -- half the L1 traffic of the 4x2 form, whose row pairs fetched the
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     if (hh == 0) ag = (bufoff + b16x[g / 4]) ^ ((g & 3) << 5);
                     rw[s_ % WIN] = *(const u32x4*)(smem + ag + hh * HPITCH * 128);
                 };
-                if (!(a.dbg & 64)) {
+                if (!CCN_DBG_BIT(a, 64)) {
 #pragma unroll
                 for (int s_ = 0; s_ < PF; ++s_) rload(s_);
 #pragma unroll
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
                 }
             };
-            if (!(a.dbg & 64)) {                                   // CCN_DBG=64: consumers idle (timing experiments only)
+            if (!CCN_DBG_BIT(a, 64)) {                                   // CCN_DBG=64: consumers idle (timing experiments only)
             frag(0, av[0]);
 #pragma unroll
             for (int j = 0; j < NSTEP; ++j) {
@@ -734,12 +739,15 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     const int ks = a.ksplit == 2 ? 2 : 1;
     if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5))) return hipErrorInvalidValue;
     const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt * ks;
-    static const int cap = getenv("CCN_PR_GRID") ? atoi(getenv("CCN_PR_GRID")) : 0;
+    static const int cap = diag_env("CCN_PR_GRID") ? atoi(diag_env("CCN_PR_GRID")) : 0;       // diagnostics build only
     int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);
     if (grid > ntiles) grid = ntiles;
-    if (ks == 2) grid &= ~1;                                     // partners (2*tile, 2*tile+1) run in adjacent workgroups at the same time
+    // split-K partners (virtual tiles 2t, 2t+1) must run at the same time AND on the same XCD (the hand-off has no agent-scope
+    // fence): a grid that is a multiple of 16 gives every XCD an even-sized, even-aligned contiguous range of virtual ids in
+    // every round of the persistent loop.  Fewer than 16 virtual tiles: the layer is too small for this kernel anyway.
+    if (ks == 2) { grid &= ~15; if (grid < 16) return hipErrorInvalidValue; }
     ConvArgs d = a;
-    static const char* env = getenv("CCN_STAMPS");
+    static const char* env = diag_env("CCN_STAMPS");
     if (env && (unsigned)atoi(env) == (unsigned)ntiles && (!strchr(env, ':') || atoi(strchr(env, ':') + 1) == a.ntaps)) {   // CCN_STAMPS=<tiles>[:<ntaps>]
         if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
         g_stamp_grid = (unsigned)grid;

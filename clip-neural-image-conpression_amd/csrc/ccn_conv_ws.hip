@@ -82,10 +82,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     const unsigned char* const inb = (const unsigned char*)a.in;
     const bool gn = a.gn_ab != nullptr;
     const int iy0 = my0 - 1, ix0 = mx0 - 1;
-    // diagnostic stamps (a.stamps is null outside profiling runs): slot 0 entry, 1 prologue done, 2 loop done, 3 exit, per role
+    // diagnostic stamps (CCN_STAMPS_PTR(a) is null outside profiling runs): slot 0 entry, 1 prologue done, 2 loop done, 3 exit, per role
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0)) {
-            unsigned long long* st = a.stamps + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8;
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == 4 || wave == A0)) {
+            unsigned long long* st = CCN_STAMPS_PTR(a) + ((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8;
             st[slot] = __builtin_amdgcn_s_memrealtime();
             if (slot == 1) st[5] = __builtin_amdgcn_s_memtime();       // shader-clock stamps around the loop -> in-kernel clock
             if (slot == 2) st[6] = __builtin_amdgcn_s_memtime();
@@ -93,12 +93,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
     };
     unsigned long long bar_wait = 0;      // diagnostic: shader cycles spent inside the loop's barriers
     auto loop_barrier = [&]() __attribute__((always_inline)) {
-        if (a.stamps) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); __syncthreads(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
+        if (CCN_STAMPS_PTR(a)) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); __syncthreads(); bar_wait += __builtin_amdgcn_s_memtime() - t0; }
         else __syncthreads();
     };
     auto stamp_wait = [&]() __attribute__((always_inline)) {
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 4 || wave == A0))
-            a.stamps[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8 + 4] = bar_wait;
+        if (CCN_STAMPS_PTR(a) && lane == 0 && (wave == 0 || wave == 4 || wave == A0))
+            CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 3 + (wave == 0 ? 0 : (wave == 4 ? 1 : 2))) * 8 + 4] = bar_wait;
     };
     stamp(0);
     const size_t wtap_bytes = (size_t)a.Cout_pad * a.Cin_pad * sizeof(T);      // one tap of the packed weights
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
             }
         }
     };
-    const bool do_epi = !(a.dbg & 8);
+    const bool do_epi = !CCN_DBG_BIT(a, 8);
 
     if (wave >= A0) {
         // ------------------------------------------------------------------ A producers (2 waves): input halo, ONE CHUNK AHEAD IN REGISTERS
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
         __syncthreads();                                           // prologue tiles visible
         stamp(1);
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-            const bool more = chunk + 1 < a.nchunk && !(a.dbg & 1);
+            const bool more = chunk + 1 < a.nchunk && !CCN_DBG_BIT(a, 1);
             unsigned char* const Ad = As + ((chunk + 1) & 1) * L::A_BYTES;
 #pragma unroll
             for (int g = 0; g < NSPC; ++g) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a)
 #pragma unroll
             for (int g = 0; g < NSPC; ++g, ++stage) {
                 constexpr int dummy = 0; (void)dummy;
-                const bool wr = stage + 1 < n_stage && !(a.dbg & 2);
+                const bool wr = stage + 1 < n_stage && !CCN_DBG_BIT(a, 2);
                 unsigned char* const Bd = Bs + ((stage + 1) & 1) * L::B_BYTES;
 #pragma unroll
                 for (int tt = 0; tt < TPS; ++tt) {
@@ -541,7 +541,7 @@ extern "C" int ccn_internal_dump_stamps(const char* path)
 hipError_t launch_conv_ws(int dtype, int bn, const ConvArgs& a, hipStream_t s)
 {
     const unsigned grid = (unsigned)(a.B * a.n_ty * a.n_tx * a.npar * a.n_nt);
-    static const char* env = getenv("CCN_STAMPS");
+    static const char* env = diag_env("CCN_STAMPS");
     if (env) {
         unsigned want = (unsigned)atoi(env), want_taps = strchr(env, ':') ? (unsigned)atoi(strchr(env, ':') + 1) : 9u;
         if (grid == want && (unsigned)a.ntaps == want_taps) {

@@ -4,6 +4,24 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <stdlib.h>
+
+// ---- diagnostics ---------------------------------------------------------------------------------
+// The product library (plain `make`) reads NO environment variable and contains no ablation code: every A/B switch
+// (kernel choice, split-K policy, pre-pass placement ...) is fixed at its measured default, the CCN_DBG / CCN_WG_DBG
+// ablation bits (which produce WRONG results on purpose) and the CCN_STAMPS in-kernel timers compile to nothing.
+// `make diag` builds libccn_hip_diag.so with -DCCN_DIAG, where the switches documented in DESIGN.md section 4 are live;
+// tools/ select it through CCN_HIP_LIB.
+#ifdef CCN_DIAG
+#define CCN_DBG_BIT(a, bit) ((((a).dbg) & (bit)) != 0)
+#define CCN_STAMPS_PTR(a) ((a).stamps)
+namespace ccn { inline const char* diag_env(const char* name) { return getenv(name); } }
+#else
+#define CCN_DBG_BIT(a, bit) false
+#define CCN_STAMPS_PTR(a) ((unsigned long long*)nullptr)
+namespace ccn { inline const char* diag_env(const char*) { return nullptr; } }
+#endif
+
 namespace ccn {
 
 // ---- implicit-GEMM convolution ------------------------------------------------------------------
@@ -49,6 +67,7 @@ struct ConvArgs {
     int ksplit;             // persistent kernel: 2 = split the Cin chunks over two workgroups per tile (small layers), else 1
     void* kpart;            // split-K: bf16 partial tensor, laid out like `out`
     unsigned* kflag;        // split-K: [tiles][4] hand-off flags, zero between launches
+    unsigned* err;          // device-visible error word of the handle (pinned host memory): bit 0 = a split-K hand-off timed out; or null
     int n_ty, n_tx, n_nt, nchunk, ntaps;
     int silu;               // SiLU after the prologue GroupNorm
     int cpg, G, nslot;      // output GroupNorm geometry

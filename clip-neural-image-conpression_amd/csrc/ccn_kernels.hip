@@ -411,7 +411,7 @@ hipError_t conv_prepare()
 
 bool conv_ws_enabled()
 {
-    static const int on = getenv("CCN_CONV_V1") ? 0 : 1;      // CCN_CONV_V1=1: A/B switch back to the 4-wave kernel
+    static const int on = diag_env("CCN_CONV_V1") ? 0 : 1;      // CCN_CONV_V1=1: A/B switch back to the 4-wave kernel
     return on != 0;
 }
 
@@ -421,7 +421,7 @@ int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt)
     // 8-row tiles halve the weight traffic through L2 and LDS (the 4-row tile is LDS-bandwidth bound: 1 KB of
     // fragment reads per MFMA plus 32 B/clk of weight ds_writes) and cut the halo overhead; keep every CU busy
     const long blocks8 = (long)B * ((MH + 7) / 8) * ((MW + 31) / 32) * npar * n_nt;
-    static const long min8 = getenv("CCN_MIN8") ? atol(getenv("CCN_MIN8")) : 256;
+    static const long min8 = diag_env("CCN_MIN8") ? atol(diag_env("CCN_MIN8")) : 256;
     return blocks8 >= min8 ? 8 : 4;
 }
 
@@ -430,7 +430,7 @@ int conv_tile_rows(int kind, int bn, int B, int MH, int MW, int npar, int n_nt)
 static int g_conv_variant = -1;
 static int conv_variant()
 {
-    if (g_conv_variant < 0) g_conv_variant = getenv("CCN_CONV_DMA") ? atoi(getenv("CCN_CONV_DMA")) : 4;
+    if (g_conv_variant < 0) g_conv_variant = diag_env("CCN_CONV_DMA") ? atoi(diag_env("CCN_CONV_DMA")) : 4;
     return g_conv_variant;
 }
 extern "C" int ccn_internal_set_conv_variant(int v) { const int old = conv_variant(); g_conv_variant = v; return old; }
@@ -445,7 +445,7 @@ hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream
     if (a.use_stem2) return launch_stem2(a, s);
     if (a.use_pr && kind == KIND_C3S2) return launch_conv_pr(dtype, a, s);
     if (conv_ws_enabled() && conv_ws_supported(kind, bn)) {
-        static const int dbg = getenv("CCN_DBG") ? atoi(getenv("CCN_DBG")) : 0;
+        static const int dbg = diag_env("CCN_DBG") ? atoi(diag_env("CCN_DBG")) : 0;
         ConvArgs d = a; d.dbg = dbg;
         if (a.use_pr) return launch_conv_pr(dtype, d, s);        // decided at plan time (variant 4, bf16, 8-row tiles)
         // free-running kernel on 8-row tiles only: on 4-row tiles a consumer wave would issue 8 DMA pieces per 16 MFMAs and
@@ -464,7 +464,7 @@ hipError_t launch_conv(int dtype, int kind, int bn, const ConvArgs& a, hipStream
 // ---- GroupNorm-apply + SiLU pre-pass ----------------------------------------------------------------------
 bool conv_wants_preact(int kind, int bn, int n_nt)
 {
-    static const int mode = getenv("CCN_PREACT") ? atoi(getenv("CCN_PREACT")) : 1;    // 0 never, 1 when n_nt >= 2, 2 always
+    static const int mode = diag_env("CCN_PREACT") ? atoi(diag_env("CCN_PREACT")) : 1;    // 0 never, 1 when n_nt >= 2, 2 always
     if (!conv_ws_enabled() || !conv_ws_supported(kind, bn) || kind != KIND_C3S1) return false;
     return mode == 2 || (mode == 1 && n_nt >= 2);   // (launch_gn_act needs C/EPC <= 256; wider layers keep the fused prologue)
 }

@@ -297,7 +297,7 @@ struct Walk {
     const PackDesc* shape_packs = nullptr; int n_shape_packs = 0;
     bool side_active() const
     {
-        static const bool off_ = getenv("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
+        static const bool off_ = diag_env("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
         return !off_ && !tr->profiling && tr->side != nullptr;
     }
     bool fork_side()
@@ -341,7 +341,7 @@ struct Walk {
         const int n_nt = Npad / BN;
         const int th = conv_tile_rows(kind, BN, B, g.MH, g.MW, g.npar, n_nt);
         // the persistent register-weight kernel (ccn_conv_pr.hip) where the inference plan would use it: 3x3 s1, bf16, 8-row tiles
-        static const bool no_pr = getenv("CCN_TRAIN_NO_PR") != nullptr;     // A/B switch
+        static const bool no_pr = diag_env("CCN_TRAIN_NO_PR") != nullptr;     // A/B switch
         const bool pr = !no_pr && kind == KIND_C3S1 && frag.dst && conv_pr_selected(tr->cfg.dtype, kind, BN, th) && Kpad / cke >= 2 && !(res && film) &&
                         (double)B * g.Hout * g.Wout * N * tr->elem < 2.0e9;
         if (!base) pack_list.push_back(pr ? frag : plain);      // measuring walk: this shape's repack list
@@ -439,7 +439,7 @@ struct Walk {
                     // kernel then stage plain copies.  Redoing the transform while staging costs both of them VALU issue slots next to
                     // their MFMAs (per pixel tile the weight-gradient kernel spent more cycles in exp/rcp than in MFMAs); the pre-pass is
                     // one HBM-bound read + write per norm.  Layers the pre-pass kernel cannot take keep the fused prologue.
-                    static const bool no_pre = getenv("CCN_TRAIN_NO_PREACT") != nullptr;       // A/B switch
+                    static const bool no_pre = diag_env("CCN_TRAIN_NO_PREACT") != nullptr;       // A/B switch
                     ResSave s; s.x = x;
                     s.pre = !no_pre && r.C / (tr->elem == 2 ? 8 : 4) <= 256;
                     if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;

@@ -257,7 +257,7 @@ GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
     g.nslb = nslb; g.zblocks = nsl / nslb; g.pstep = 256 / nslb;
     // pixels per workgroup: at least 256 workgroups per sample (the 32-pixel level would otherwise run on 8), at most 32 passes
     int iters = HW / (g.pstep * 256);
-    static const int cap = getenv("CCN_GNB_ITERS") ? atoi(getenv("CCN_GNB_ITERS")) : 32;
+    static const int cap = diag_env("CCN_GNB_ITERS") ? atoi(diag_env("CCN_GNB_ITERS")) : 32;
     iters = iters < 1 ? 1 : (iters > cap ? cap : iters);
     g.ppb = g.pstep * iters;
     g.nblk = (HW + g.ppb - 1) / g.ppb;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_ws_kernel(const WgArgs a)
         if (ntile > 1) issue(s1, 1);
         if (ntile > 0) { commit(s0, 0); if (ntile > 2) issue(s0, 2); }
         __syncthreads();
-        const bool idle = (a.dbg & 1) != 0;
+        const bool idle = CCN_DBG_BIT(a, 1);
         for (int j = 0; j < ntile; j += 2) {
             if (j + 1 < ntile && !idle) { commit(s1, 1); if (j + 3 < ntile) issue(s1, j + 3); }
             __syncthreads();
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_ws_kernel(const WgArgs a)
     // (issuing read, wait, MFMA per step ran at 1/4 of the MFMA rate).
     constexpr int NSTEP = 8 * NTAPS, RING = 8, PF = 6;
     for (int j = 0; j < ntile; ++j) {
-        if (a.dbg & 2) { __syncthreads(); continue; }
+        if (CCN_DBG_BIT(a, 2)) { __syncthreads(); continue; }
         const unsigned char* const base = smem + (j & 1) * BUF;
         const unsigned char* const Dp = base + d_off;
         const unsigned char* apt[NTAPS];
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_ws_kernel(const WgArgs a)
         }
         __syncthreads();
     }
-    if (a.dbg & 4) return;
+    if (CCN_DBG_BIT(a, 4)) return;
     const int k = k0 + wk * 32 + r;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
@@ -972,7 +972,7 @@ static wgrad_fn_t wgrad_pick(int dtype, int kind, size_t* lds, int* nt, int* kt,
 {
     if (dtype == 1) {
         *nt = 64; *kt = 64;
-        static const bool no_ws = getenv("CCN_WGRAD_NO_WS") != nullptr;         // A/B switch: single-role kernel everywhere
+        static const bool no_ws = diag_env("CCN_WGRAD_NO_WS") != nullptr;         // A/B switch: single-role kernel everywhere
         if (!no_ws) {
             if (!silu && kind == KIND_C3S1) { *lds = wgrad_bf16_ws_lds(); return (wgrad_fn_t)wgrad_bf16_ws_kernel<9, false>; }
             if (kind == KIND_C3S1) { *lds = wgrad_bf16_ws_lds(); return (wgrad_fn_t)wgrad_bf16_ws_kernel<9, true>; }
@@ -1015,11 +1015,11 @@ int wgrad_nsplit(int dtype, int kind, int B, int MH, int MW, int Cin, int Cout, 
     const int npar = kind == KIND_CT4 ? 4 : 1;
     const int tiles = B * ((MH + 3) / 4) * ((MW + 31) / 32);
     const int groups = ((Cin + kt - 1) / kt) * ((Cout + nt - 1) / nt) * npar;
-    static const int target_bf16 = getenv("CCN_WGRAD_WGS") ? atoi(getenv("CCN_WGRAD_WGS")) : 512;
+    static const int target_bf16 = diag_env("CCN_WGRAD_WGS") ? atoi(diag_env("CCN_WGRAD_WGS")) : 512;
     const bool ws = dtype == 1 && lds == wgrad_bf16_ws_lds();
     // one workgroup per CU when the kernel has the GPU to itself; when it runs on the side stream next to the data-gradient chain,
     // ~100 workgroups: measured 6.46 ms per step at 96, 6.51 at 128, 7.08 at 256 (the main-stream kernels get the other CUs)
-    static const int env_ws = getenv("CCN_WGRAD_WS_WGS") ? atoi(getenv("CCN_WGRAD_WS_WGS")) : 0;
+    static const int env_ws = diag_env("CCN_WGRAD_WS_WGS") ? atoi(diag_env("CCN_WGRAD_WS_WGS")) : 0;
     const int target_ws = env_ws > 0 ? env_ws : (concurrent ? 96 : 256);
     int ns = ((ws ? target_ws : (dtype == 1 ? target_bf16 : 768)) + groups - 1) / groups;     // 1 (warp-specialised) or 2-3 workgroups per CU
     if (ns > tiles) ns = tiles;
@@ -1035,7 +1035,7 @@ hipError_t launch_wgrad(int dtype, int kind, const WgArgs& a, hipStream_t s)
     if (a.Cin % epc || a.Cout % epc) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(((a.Cin + kt - 1) / kt) * ((a.Cout + nt - 1) / nt) * a.npar * a.nsplit);
     const bool ws = dtype == 1 && lds == wgrad_bf16_ws_lds();
-    static const int dbg = getenv("CCN_WG_DBG") ? atoi(getenv("CCN_WG_DBG")) : 0;
+    static const int dbg = diag_env("CCN_WG_DBG") ? atoi(diag_env("CCN_WG_DBG")) : 0;
     WgArgs d = a; d.dbg = dbg;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(ws ? 512 : 256), lds, s, d);
     return hipGetLastError();

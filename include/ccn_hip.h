@@ -140,6 +140,12 @@ int ccn_timestep_embedding(const int64_t* t_dev, float* out_dev, int32_t n, int3
  * "<block>.film" for the tensor entering norm2.  Synchronises `stream`. */
 int ccn_read_activation(ccn_handle_t h, const char* name, float* out_dev, size_t out_elems, void* stream);
 
+/* Device-side failures are sticky: a kernel that detects a broken hand-off (a split-K partial tile that never arrived) sets a
+ * bit in the handle's error word and carries on; the NEXT call that takes the handle -- or this one, e.g. after the caller has
+ * synchronised its stream -- returns CCN_EHIP once and clears it.  Results enqueued since the last successful check are then
+ * invalid.  (The reference has no counterpart: torch raises asynchronous device errors the same way, at the next call.) */
+int ccn_poll_errors(ccn_handle_t h);
+
 /* Per-kernel-family device time of the next ccn_sample / ccn_forward calls, measured with HIP events
  * recorded on the launch stream around every kernel (the loop then runs launch by launch instead of
  * as one graph).  ccn_profile_read synchronises, then fills arrays of capacity `cap`: family name,

@@ -261,7 +261,8 @@ def test_c2_bf16_reported_deviation(golden, synth, c2_sd):
     x = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0).sample(net, z, (1, 3, 256, 256), steps=50, x_T=xT)
     d = np.abs(x[0, :, ::4, ::4].cpu().numpy() - g["x_final.sub"])
     print(f"C2 bf16: forward max-abs {err:.3e}; 50-step max-abs {d.max():.3e} mean-abs {d.mean():.3e}")
-    assert d.mean() < 0.15 and np.isfinite(d).all()
+    # measured on MI355X (round 2): max-abs 0.21, mean-abs 0.032; the bound is 2x the measured mean
+    assert d.mean() < 0.065 and d.max() < 0.6 and np.isfinite(d).all()
 
 
 def test_c2_batch8_fp32_large_tiles_vs_reference(golden, synth, c2_sd):
@@ -372,3 +373,44 @@ def test_c2_architecture_odd_shapes(synth, c2_sd, B, H, W):
     d16 = maxerr(e16, e32)
     print(f"B={B} {H}x{W}: fp32 vs oracle {d32:.2e}; bf16 vs fp32 {d16:.3e}")
     assert torch.isfinite(e16).all() and d16 < 2e-2, (B, H, W, d16)
+
+
+
+def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
+    """The exact bench.py workload (C2: batch 8, 256 px, 50 steps, bf16, fused graph on the persistent kernel) against
+    (a) the reference's device='cpu' run of record 0 (golden), (b) this library's fp32 parity mode on all 8 rows, and
+    (c) PSNR against the synthetic originals in both modes -- north_star asks for PSNR within 0.1 %.
+    Measured on MI355X (round 2; the same numbers are printed in bench.py's `parity` block on every run):
+      fp32 mode row 0 vs reference: max-abs 2.9e-4 (gate 1e-3: met);
+      bf16 row 0 vs reference: max-abs 0.21, mean-abs 0.032; bf16 vs fp32 mode, all rows: max-abs 0.32, mean-abs 0.032
+      (the reference's own bf16-autocast run deviates 0.30 / 0.037 from its fp32 run on these weights);
+      PSNR: 11.353 dB (fp32 mode) vs 11.364 dB (bf16): per-record relative delta 0.10 % mean, 0.15 % max --
+      bf16 mode does NOT meet the 0.1 % PSNR gate on these weights (the clamp in the DDIM update turns zero-mean bf16
+      noise into a slight contrast loss, and PSNR against an unrelated original rewards that); fp32 mode does.
+    Bounds asserted: 2x the measured deviations; the 0.1 % gate itself is asserted for the fp32 mode against the reference."""
+    from clip_feature_codec.eval.metrics import psnr
+    g = golden("c2_sample.npz")
+    B, S, T = 8, 256, 50
+    z = to_dev(synth.synth_z(B)); xT = to_dev(synth.start_noise(range(B), S, seed_base=100))
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0)
+    net16 = make_net(c2_sd, 128, (1, 2, 2), dtype="bf16")
+    x16 = sampler.sample(net16, z, (B, 3, S, S), steps=T, x_T=xT)
+    x32 = sampler.sample(make_net(c2_sd, 128, (1, 2, 2)), z, (B, 3, S, S), steps=T, x_T=xT)
+    d32 = np.abs(x32[0, :, ::4, ::4].cpu().numpy() - g["x_final.sub"])
+    d16 = np.abs(x16[0, :, ::4, ::4].cpu().numpy() - g["x_final.sub"])
+    dall = (x16 - x32).abs()
+    assert d32.max() < TOL_E2E_FP32, d32.max()                  # batch 8 fp32 mode: the headline gate, on the bench batch
+    assert d16.mean() < 0.065 and d16.max() < 0.6, (d16.mean(), d16.max())
+    assert float(dall.mean()) < 0.065 and float(dall.max()) < 0.8, (float(dall.mean()), float(dall.max()))
+    orig = [synth.synth_image(i, S).astype(np.float32).transpose(2, 0, 1) / 127.5 - 1.0 for i in range(B)]
+    r16, r32 = x16.clamp(-1, 1).cpu().numpy(), x32.clamp(-1, 1).cpu().numpy()
+    p16 = np.array([psnr(orig[k], r16[k]) for k in range(B)]); p32 = np.array([psnr(orig[k], r32[k]) for k in range(B)])
+    rel = np.abs(p16 - p32) / np.abs(p32)
+    print(f"C2 bench workload: fp32 row0 vs ref {d32.max():.2e}; bf16 row0 vs ref max {d16.max():.3f} mean {d16.mean():.4f}; "
+          f"bf16 vs fp32 all rows max {float(dall.max()):.3f} mean {float(dall.mean()):.4f}; "
+          f"PSNR fp32 {p32.mean():.4f} dB bf16 {p16.mean():.4f} dB, rel delta mean {rel.mean():.2e} max {rel.max():.2e} "
+          f"(0.1 % gate {'met' if rel.max() <= 1e-3 else 'NOT met'} by bf16 mode)")
+    assert rel.max() < 3e-3, rel                                # 2x the measured 0.15 %
+    # fp32 mode vs the reference on record 0: PSNR within 0.1 % follows from max-abs < 1e-3 (uint8 truncation moves few pixels)
+    torch.cuda.synchronize()
+    net16.native().poll_errors()                                # no device-side failure (split-K hand-off timeout) was flagged
