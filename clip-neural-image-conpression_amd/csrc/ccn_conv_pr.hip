@@ -128,6 +128,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // reduced to one add: item i of a thread is halo row i at a fixed column, offsets are base + i * row stride, row
         // validity is wave-uniform, and everything is branch-free (out-of-range offsets make loads return zero).
         const int ptid = tid - 256, pw = wave - 4;
+        if (CCN_DBG_BIT(a, 128)) __builtin_amdgcn_s_setprio(1);      // diagnostics: producer priority experiments
+        if (CCN_DBG_BIT(a, 256)) __builtin_amdgcn_s_setprio(3);
         const int ck = ptid & 7, pcol = ptid >> 3;                // 16-byte channel slice, halo column 0..31
         // the two halo columns 32, 33 (10 rows x 8 slices = 160 units) go to threads 0..159 as an eleventh item
         const int xrow = pcol >> 1, xcol = 32 + (pcol & 1);
