@@ -30,14 +30,15 @@ namespace ccn {
 
 namespace {
 
-struct PrLds {
-    static constexpr int HROWS = 10, HPITCH = 34;
-    static constexpr int A_BYTES = HROWS * HPITCH * 128;       // one Cin chunk of the halo tile (43520)
+template <int TH_> struct PrLdsT {
+    static constexpr int HROWS = TH_ + 2, HPITCH = 34;
+    static constexpr int A_BYTES = HROWS * HPITCH * 128;       // one Cin chunk of the halo tile (43520 at 8 rows)
     static constexpr int SP = 272;                              // staging pitch in bytes: 128 bf16 channels + 16
-    static constexpr int STG_BYTES = 256 * SP;                  // 256 pixels
+    static constexpr int STG_BYTES = TH_ * 32 * SP;             // TH x 32 pixels
     static constexpr int CHS_BYTES = 4 * 128 * 2 * 4;           // per producer wave: per-channel (sum, sum of squares)
     static constexpr int TOTAL = 2 * A_BYTES + STG_BYTES + CHS_BYTES;
 };
+typedef PrLdsT<8> PrLds;
 static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 
 }  // namespace
@@ -52,15 +53,22 @@ static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 // waits for that flag (bounded spin, acquire), adds the partial like a residual and writes the output and the GroupNorm
 // statistics.  Partner workgroups are neighbours in the virtual tile order (same XCD) and never wait on each other in the
 // other direction, so the launch cannot deadlock as long as its <= #CUs workgroups are co-resident.
-template <int NTAPS, int D, int MODE>
+//
+// TH = 4 (3x3 stride 1 only): the same kernel on tiles of 4 rows for layers with fewer than #CUs tiles of 8 rows (the 32-pixel
+// level at C2: 128 -> 256 tiles) -- every CU gets a tile without splitting K (no hand-off between workgroups), the producers
+// stage 6 halo rows instead of 10, a consumer wave owns 4 rows x 32 channels (12 MFMAs per (dx, k-slice) group per 3 weight
+// fragments: twice the weight stream per MFMA of the 8-row form, still from L2).
+template <int NTAPS, int D, int MODE, int TH = 8>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
+    static_assert(TH == 8 || (TH == 4 && NTAPS == 9), "4-row tiles: 3x3 stride-1 form only");
     constexpr bool COLW = true;                                // 3x3: column-per-wave consumers (false: the 4x2 fragment form)
     constexpr bool RES = MODE == 1;                            // residual registers: MODE 1 always, MODE 2 in the second K half
     constexpr bool RR = MODE != 0;
     typedef __bf16 T;
     constexpr int MF = 4, NF = 2;
-    constexpr int TH = 8, BN = 128;
+    constexpr int BN = 128;
+    constexpr int HROWS = TH + 2;
     constexpr int EPC = 8, CKE = 64;
     constexpr int NSTEP = NTAPS * 4;                           // step = tap * 4 + kk (one 16-byte K slice per lane half)
     // NTAPS == 2: the stride-2 3x3 conv.  Its 9 taps fall on the four parity planes P[py][px](i, j) = in(2i+py, 2j+px) of the
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     constexpr bool S2 = NTAPS == 2;
     constexpr int IS = S2 ? 2 : 1;                             // input stride of the staged plane
     static_assert(NSTEP % D == 0, "the register ring must wrap at the chunk boundary");
-    using L = PrLds;
+    using L = PrLdsT<TH>;
     constexpr int HPITCH = L::HPITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const stg = smem + 2 * L::A_BYTES;
@@ -131,10 +139,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         if (CCN_DBG_BIT(a, 128)) __builtin_amdgcn_s_setprio(1);      // diagnostics: producer priority experiments
         if (CCN_DBG_BIT(a, 256)) __builtin_amdgcn_s_setprio(3);
         const int ck = ptid & 7, pcol = ptid >> 3;                // 16-byte channel slice, halo column 0..31
-        // the two halo columns 32, 33 (10 rows x 8 slices = 160 units) go to threads 0..159 as an eleventh item
+        // the two halo columns 32, 33 (HROWS rows x 8 slices = 160 units at 8 rows) go to threads 0..HROWS*16-1 as one more item
         const int xrow = pcol >> 1, xcol = 32 + (pcol & 1);
-        const bool xthr = ptid < 160;
-        constexpr int AIT = 11;
+        const bool xthr = ptid < HROWS * 16;
+        constexpr int AIT = HROWS + 1;
         u32x4 areg[AIT];
         GnCoef<T> gk;
         unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
@@ -186,15 +194,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             // halo rows inside the image: [r_lo, r_hi) (wave-uniform), as a bit mask for the padding-stays-zero select in dump()
             const int first = IS * iy0 + py;                                      // input row of halo row 0
             const int r_lo = first < 0 ? (-first + IS - 1) / IS : 0;
-            int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > 10 ? 10 : (r_hi < 0 ? 0 : r_hi);
+            int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > HROWS ? HROWS : (r_hi < 0 ? 0 : r_hi);
             rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
+            for (int i = 0; i < HROWS; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
             {
                 const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
                 xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
                 const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
-                areg[10] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
+                areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
             }
         };
         auto request = [&]() __attribute__((always_inline)) { prep(); issue(); };
@@ -206,15 +214,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
                 u32x4 v = areg[i];
-                const bool ok = i < 10 ? (((rowm >> i) & 1u) && colv) : xv;
+                const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
                 if (gn) {
                     const u32x4 tr = gk.template apply<true>(v);
                     v = u32x4{0u, 0u, 0u, 0u};                                  // padding stays zero
                     if (ok) v = tr;                                             // (exec-masked move: scalar ops instead of 4 selects)
                 }
-                const int px = i < 10 ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
-                const int sw = i < 10 ? (pc >> 1) : 0;                       // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
-                if (i < 10 || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
+                const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
+                const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
+                if (i < HROWS || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
                 if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
             }
         };
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const unsigned char* const resb = (const unsigned char*)a.res;
         const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
         float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
+        constexpr int NQ = TH / 2;               // epilogue batches of 4 items (two tile rows each)
         u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
         f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
         int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0, e_kh = 0, e_tile = 0;
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 unsigned eb = e_base; asm volatile("" : "+v"(eb));
                 int sbase = pr * L::SP + o16 * 16; asm volatile("" : "+v"(sbase));
 #pragma unroll
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (RR) { if (q + 2 < 4) res_batch(q + 2, rr[q & 1]); }    // refill the buffer just consumed, one batch ahead
+                if constexpr (RR) { if (q + 2 < NQ) res_batch(q + 2, rr[q & 1]); }   // refill the buffer just consumed, one batch ahead
             }
             if (first) {
                 // publish the partial tile: every store of this wave visible at agent scope, then its flag
@@ -425,10 +434,16 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
             if (epi) epilogue();
             if (CCN_STAMPS_PTR(a)) t_b += __builtin_amdgcn_s_memtime() - t0;
+            // last iteration (always the LAST chunk of a tile, nck >= 2, so no epilogue ran above and its registers are free):
+            // fetch the last tile's bias / FiLM / first residual rows now, behind the consumers' last chunk, instead of after the
+            // final barrier where nothing hides their latency.  (The second half of a split-K pair first has to see its
+            // partner's flag; that wait stays behind the barrier so that it cannot hold this workgroup's consumers up.)
+            const bool early = k + 1 == ktotal && !(ks == 2 && e_kh == 1);
+            if (early) epi_request();
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
             if (++c == nck) { c = 0; ++ti; }
         }
-        epi_request();
+        if (ks == 2 && e_kh == 1) epi_request();
         epilogue();                                                // last tile
         stamp(2); stamp_cycles();
         return;
@@ -443,9 +458,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // (output row, dy) pairs the moment it arrives (row hh feeds output rows hh, hh-1, hh-2), so only the prefetch window is live.
         constexpr int WIN = 6, PF = 4;                             // row-fragment window / prefetch distance (rows)
         constexpr int DG = 3;                                      // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
-        constexpr int NG = 12, NROW = 10;
+        constexpr int NG = 12, NROW = HROWS;
         static_assert((NG * NROW) % WIN == 0 && NG % DG == 0, "static ring indexing");
-        f32x16 acc[8];
+        f32x16 acc[TH];
         const int n32 = a.Cout_pad / 32;
         constexpr unsigned COLB = 36 * 1024;
         const unsigned wtotal = (unsigned)((size_t)a.nchunk * n32 * COLB);
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
             const int tile = vt_tile(v), c0 = vt_kh(v) * nck;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < TH; ++i)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
             for (int chunk = 0; chunk < nck; ++chunk, ++k) {
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int i = hh - dy;
-                        if (i >= 0 && i < 8) { mfma16<T>(acc[i], bq[g % DG][dy], rw[s_ % WIN]); ++nm; }
+                        if (i >= 0 && i < TH) { mfma16<T>(acc[i], bq[g % DG][dy], rw[s_ % WIN]); ++nm; }
                     }
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 if (chunk + 1 == nck) {
                     // hand the tile to the producers: bf16 staging, 8 bytes (4 channels) per store
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < TH; ++i)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x16& c = acc[i];
@@ -541,6 +556,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         stamp(2); stamp_cycles();
         return;
     }
+    static_assert(NTAPS == 9 || TH == 8, "the 4x2 fragment form works on 8-row tiles");
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[MF][NF];
     // byte offset of this lane's 16-byte slice (k-slice 0) of halo pixel (row_lin = hy*HPITCH + hx): slice index h ^ (hx >> 1)
@@ -689,14 +705,18 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #define PR_D 6
 #endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
-static pr_fn_t pick_pr(int ntaps, int mode)
+static pr_fn_t pick_pr(int ntaps, int mode, int th = 8)
 {
+    if (ntaps == 9 && th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 4> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4>);
     if (ntaps == 9) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0>);
     if (ntaps == 2) return mode == 1 ? (pr_fn_t)conv_pr_kernel<2, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<2, 8, 2> : (pr_fn_t)conv_pr_kernel<2, 8, 0>);
     return mode == 1 ? (pr_fn_t)conv_pr_kernel<4, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<4, 8, 2> : (pr_fn_t)conv_pr_kernel<4, 8, 0>);
 }
 
-bool conv_pr_supported(int kind, int bn, int th) { return (kind == KIND_C3S1 || kind == KIND_CT4 || kind == KIND_C3S2) && bn == 128 && th == 8; }
+bool conv_pr_supported(int kind, int bn, int th)
+{
+    return bn == 128 && (((kind == KIND_C3S1 || kind == KIND_CT4 || kind == KIND_C3S2) && th == 8) || (kind == KIND_C3S1 && th == 4));
+}
 
 static int g_cus = 0;
 hipError_t conv_pr_prepare()
@@ -707,6 +727,10 @@ hipError_t conv_pr_prepare()
             e = hipFuncSetAttribute((const void*)pick_pr(ntaps, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
             if (e != hipSuccess) return e;
         }
+    for (int mode = 0; mode < 3; ++mode) {
+        e = hipFuncSetAttribute((const void*)pick_pr(9, mode, 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLdsT<4>::TOTAL);
+        if (e != hipSuccess) return e;
+    }
     int dev = 0;
     e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -737,7 +761,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // a.ntaps as the persistent kernel sees the layer: 9 (3x3 s1), 4 (ConvTranspose parity), 2 (3x3 s2 as plane passes, nchunk = 5 x channel chunks)
     const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
     const bool s2 = a.ntaps == 2 && a.npar == 1 && a.OS == 1 && !a.gn_ab && (a.nchunk % 5) == 0;
-    if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || a.th != 8 || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
+    if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || !(a.th == 8 || (a.th == 4 && c3)) || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
     const int ks = a.ksplit == 2 ? 2 : 1;
     if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5))) return hipErrorInvalidValue;
     const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt * ks;
@@ -755,7 +779,8 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
         g_stamp_grid = (unsigned)grid;
         d.stamps = g_stamps;
     } else d.stamps = nullptr;
-    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res ? 1 : (ks == 2 ? 2 : 0)), dim3((unsigned)grid), dim3(512), PrLds::TOTAL, s, d, ntiles);
+    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res ? 1 : (ks == 2 ? 2 : 0), a.th), dim3((unsigned)grid), dim3(512),
+                       a.th == 4 ? PrLdsT<4>::TOTAL : PrLds::TOTAL, s, d, ntiles);
     return hipGetLastError();
 }
 
