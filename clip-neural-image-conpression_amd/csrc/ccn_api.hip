@@ -457,8 +457,10 @@ struct PlanBuilder {
     }
 
     // conv launch; `want_part`: also emit the partial sums of the output's GroupNorm
+    // `in_norm` (instead of gn_ab): the input goes through this GroupNorm (+ SiLU) first; its finalize either becomes part of
+    // the conv launch itself (persistent kernel, see in_kernel_stats) or a gn_finalize launch in front of it
     void conv(const ConvW& cw, int family, const TensorRef& in, TensorRef& out, const float2* gn_ab, int film_off,
-              const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false)
+              const TensorRef* res, bool want_part, bool is_stem = false, bool is_head = false, const NormW* in_norm = nullptr)
     {
         ConvGeom g = conv_geom(cw, B, in.H, in.W);
         // stride-2 convs: the 4-wave kernel works on 4-row tiles; the persistent kernel (bf16) takes them on 8-row tiles as soon
@@ -475,7 +477,7 @@ struct PlanBuilder {
         std::shared_ptr<ConvArgs> ap(new ConvArgs());
         ConvArgs& a = *ap;
         a.in = in.p; a.w = cw.w; a.wfrag = cw.wfrag; a.bias = cw.bias; a.out = out.p;
-        a.gn_ab = gn_ab; a.film = nullptr; a.res = res ? res->p : nullptr;
+        a.film = nullptr; a.res = res ? res->p : nullptr;
         a.B = B; a.Hin = in.H; a.Win = in.W; a.Cin = cw.Cin; a.Cin_pad = cw.Cin_pad;
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = cw.Cout; a.Cout_pad = cw.Cout_pad;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
@@ -484,12 +486,20 @@ struct PlanBuilder {
         a.silu = 1;
         a.G = groups_for(cw.Cout); a.cpg = cw.Cout / a.G;
         a.nslot = g.n_ty * g.n_tx * g.npar * g.n_nt;
-        // the persistent kernel publishes one partial per producer wave (4 per tile)
         if (s2pr) { a.nchunk = 5 * (cw.Cin_pad / cke); a.ntaps = 2; }   // plane passes (ccn_conv_pr.hip)
         const bool pr = cw.wfrag && conv_pr_selected(h->cfg.dtype, cw.kind, cw.BN, g.th) && cw.Cin_pad / cke >= 2 && (cw.kind != KIND_C3S2 || s2pr) &&
                         (double)B * g.Hout * g.Wout * cw.Cout * h->elem < 2.0e9;
         if (!pr) a.wfrag = nullptr;
         a.use_pr = pr ? 1 : 0;
+        if (in_norm) {
+            if (pr && ksplit != 2 && cw.kind == KIND_C3S1 && in_kernel_stats(in, cw.Cin)) {
+                const int cpg_in = cw.Cin / groups_for(cw.Cin);
+                a.gs_part = in.part; a.gs_gamma = in_norm->gamma; a.gs_beta = in_norm->beta;
+                a.gs_inv_count = 1.0 / ((double)cpg_in * in.H * in.W);
+                a.gs_nsp = in.n_sp; a.gs_nnt = in.n_nt; a.gs_bn = in.bn; a.gs_cpg = cpg_in;
+            } else gn_ab = gn(in, *in_norm);                     // (pushes the finalize launch in front of this conv)
+        }
+        a.gn_ab = gn_ab;
         a.ksplit = 1;
         if (pr && ksplit == 2) {
             a.ksplit = 2;
@@ -498,7 +508,7 @@ struct PlanBuilder {
             a.kflag = (unsigned*)bump.take(fbytes);
             if (a.kflag) plan->zero_once.push_back({a.kflag, fbytes});
         }
-        if (pr) a.nslot *= 4;
+        // (the persistent kernel publishes ONE partial per tile: its four producer waves' sums are combined in LDS first)
         const bool stem2 = is_stem && cw.wfrag && stem2_supported(h->cfg.dtype, cw.Cin, cw.Cout, h->G);
         a.use_stem2 = stem2 ? 1 : 0;
         if (stem2) { a.wfrag = cw.wfrag; a.nslot = 4 * stem2_blocks(in.H, in.W, nullptr); }   // one slot per wave
@@ -508,7 +518,7 @@ struct PlanBuilder {
         if (want_part) {
             out.part = (float2*)bump.take((size_t)B * a.G * a.nslot * sizeof(float2));
             out.n_sp = g.n_ty * g.n_tx * g.npar; out.n_nt = g.n_nt; out.bn = cw.BN;
-            if (pr) { out.n_sp *= 4; out.pr = true; }       // one slot per producer wave
+            if (pr) out.pr = true;
             if (stem2) { out.n_sp = a.nslot; out.n_nt = 1; out.bn = 1 << 30; out.pr = true; }
         }
         a.part = out.part;
@@ -536,6 +546,21 @@ struct PlanBuilder {
             return launch_conv(dtype, kind, bn, k, s);
         };
         plan->ops.push_back(std::move(L));
+    }
+
+    // The persistent kernel can form the scale/shift of its input's GroupNorm itself from the producer's partial sums (every
+    // producer wave reduces 8 groups x 8 lanes): 8 groups, a thread's 8-channel slice inside one group, and few enough slots
+    // per group that the reduction (slots / 8 loads per lane, redone whenever a workgroup moves to another sample) stays
+    // cheaper than the ~6.5 us of a finalize launch + kernel boundary -- true below the 256-pixel level at C2.
+    bool in_kernel_stats(const TensorRef& t, int C) const
+    {
+        static const bool off = diag_env("CCN_NO_INSTAT") != nullptr;
+        if (off || h->cfg.dtype != CCN_DTYPE_BF16 || t.n_sp <= 0 || t.C != C) return false;
+        const int G = groups_for(C), cpg = C / G;
+        if (G != 8 || (cpg % 8) != 0) return false;
+        int nj = 1;
+        for (int g = 0; g < G; ++g) { const int n = ((g + 1) * cpg - 1) / t.bn - (g * cpg) / t.bn + 1; if (n > nj) nj = n; }
+        return (long)t.n_sp * nj <= 64;                            // 8 slots per lane: one round of loads
     }
 
     // GroupNorm finalize of tensor `t` for the norm (gamma, beta): returns the scale/shift table
@@ -609,27 +634,26 @@ struct PlanBuilder {
     TensorRef resblock(const ResW& r, const TensorRef& x, bool out_feeds_gn, int film_off = -2)
     {
         // pre-pass only where the conv kernel would redo the transform per N tile AND has no idle VALU for it: the persistent
-        // kernel's producers absorb it (CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
+        // kernel's producers absorb it up to 4 N tiles (measured at the 512-channel level of C2, 4-row tiles: 69.5 vs 68.8
+        // images/s against pre-pass + finalize-free conv; CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
         static const bool preact_pr = diag_env("CCN_PREACT_PR") != nullptr;
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
-                         (preact_pr || r.c1.Cout_pad / r.c1.BN >= 4 || !will_use_pr(r.c1, x.H, x.W));
+                         (preact_pr || r.c1.Cout_pad / r.c1.BN >= 6 || !will_use_pr(r.c1, x.H, x.W));
         static const bool fuse_act = !diag_env("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
         const bool f1 = pre && fuse_act && x.n_sp > 0, f2 = pre && fuse_act;     // (n_sp, not the pointer: null while measuring)
         TensorRef y = new_tensor(r.C, x.H, x.W);
         if (f1) { TensorRef xa = preact_fused(x, r.n1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
-        else {
+        else if (pre) {
             const float2* ab1 = gn(x, r.n1);
-            if (pre) { TensorRef xa = preact(x, ab1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true); }
-            else conv(r.c1, F_C3S1, x, y, ab1, film_off == -2 ? r.film_off : film_off, nullptr, true);
-        }
+            TensorRef xa = preact(x, ab1); conv(r.c1, F_C3S1, xa, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true);
+        } else conv(r.c1, F_C3S1, x, y, nullptr, film_off == -2 ? r.film_off : film_off, nullptr, true, false, false, &r.n1);
         plan->named[r.prefix + ".film"] = y;
         TensorRef o = new_tensor(r.C, x.H, x.W);
         if (f2) { TensorRef ya = preact_fused(y, r.n2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
-        else {
+        else if (pre) {
             const float2* ab2 = gn(y, r.n2);
-            if (pre) { TensorRef ya = preact(y, ab2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn); }
-            else conv(r.c2, F_C3S1, y, o, ab2, -1, &x, out_feeds_gn);
-        }
+            TensorRef ya = preact(y, ab2); conv(r.c2, F_C3S1, ya, o, nullptr, -1, &x, out_feeds_gn);
+        } else conv(r.c2, F_C3S1, y, o, nullptr, -1, &x, out_feeds_gn, false, false, &r.n2);
         plan->named[r.prefix] = o;
         return o;
     }

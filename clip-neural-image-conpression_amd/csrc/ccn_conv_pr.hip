@@ -103,7 +103,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto vt_kh = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v & 1) : 0; };
 
     const unsigned char* const inb = (const unsigned char*)a.in;
-    const bool gn = a.gn_ab != nullptr && !CCN_DBG_BIT(a, 32);     // CCN_DBG=32: skip the transform (timing experiments only)
+    // GroupNorm of the input: scale/shift per (sample, channel) either from the table a separate finalize launch wrote (gn_ab),
+    // or -- gs_part != null -- formed HERE from the producing kernel's partial sums (no finalize launch between two convs)
+    const bool gstat = NTAPS == 9 && MODE != 2 && a.gs_part != nullptr;       // (3x3 stride-1 layers without split-K only)
+    const bool gn = (a.gn_ab != nullptr || gstat) && !CCN_DBG_BIT(a, 32);     // CCN_DBG=32: skip the transform (timing experiments only)
     constexpr unsigned OOB = 0x7FFFFFF0u;
     auto raw_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -154,7 +157,48 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         GnCoef<T> gkn;
         int q_b = 0, q_iy0 = 0, q_ix0 = 0, q_c = 0;
         bool q_tv = false;
-        auto prep = [&]() __attribute__((always_inline)) {
+        // in-kernel finalize (gstat): every producer wave reduces the partial sums of the sample it is about to stage by itself
+        // (no cross-wave step): lane l sums slots (l & 7), (l & 7) + 8, ... of group l >> 3 -- 8 groups x 8 lanes -- in fp64 and
+        // three xor-shuffles leave (mean, 1/sqrt(var + eps)) of group l >> 3 in every lane; a thread's 8 channels lie in one
+        // group (cpg % 8 == 0, checked on the host) whose statistics it fetches with a lane permute; gamma / beta of those
+        // channels are loaded raw in prep() and folded into (scale, shift) in issue(), one dump later, so nothing waits for them.
+        float st_mean = 0.f, st_rstd = 1.f, qn_mean = 0.f, qn_rstd = 1.f;
+        int st_b = -1;
+        f32x4 qn_g[2], qn_bt[2];
+        float2 sv[8];                            // one round of partial-sum loads (stats_issue -> stats_reduce)
+        auto stats_issue = [&](int b) __attribute__((always_inline)) {
+            const int g = lane >> 3, sub = lane & 7;
+            const int cpg = a.gs_cpg, pbn = a.gs_bn, pnt = a.gs_nnt;
+            const int jlo = (g * cpg) / pbn, jhi = ((g + 1) * cpg - 1) / pbn, nj = jhi - jlo + 1;
+            const int ne = a.gs_nsp * nj;                                  // <= 64 (host: in_kernel_stats)
+            const float2* const base = a.gs_part + (size_t)(b * 8 + g) * ((size_t)a.gs_nsp * pnt);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = sub + 8 * u;
+                sv[u] = make_float2(0.f, 0.f);
+                if (e < ne) {
+                    int sp = e, j = jlo;
+                    if (nj != 1) { sp = e / nj; j = jlo + (e - sp * nj); }
+                    sv[u] = base[(size_t)sp * pnt + j];
+                }
+            }
+        };
+        auto stats_reduce = [&]() __attribute__((always_inline)) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)sv[u].x; s2 += (double)sv[u].y; }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const double mean = s1 * a.gs_inv_count;
+            double var = s2 * a.gs_inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            st_mean = (float)mean;
+            st_rstd = __builtin_amdgcn_rsqf((float)(var + 1e-5));
+        };
+        // prep() = decode (tile / chunk of the next request) + coefficients; split so that the FIRST request of the kernel can put
+        // its input loads in front of the statistics' round trip (request_first below)
+        int q_cbs = 0; bool q_cv = false, q_cv_i = false;
+        auto decode = [&]() __attribute__((always_inline)) -> bool {
             const int v = vb + rq_ti * grid;
             if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
                 q_tv = v < ntiles;
@@ -166,11 +210,35 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             }
             q_c = vt_kh(v) * nck + rq_c;
             const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
-            const bool cv = q_tv && cb < a.Cin;
-            gkn.load(a.gn_ab + (size_t)q_b * a.Cin + (cv ? cb : 0), gn && cv);
+            q_cv = q_tv && cb < a.Cin;
+            q_cbs = q_cv ? cb : 0;
+            const bool fresh = gstat && rq_c == 0 && q_tv && q_b != st_b;  // wave-uniform: statistics of another sample needed
             if (++rq_c == nck) { rq_c = 0; ++rq_ti; }
+            return fresh;
         };
-        auto issue = [&]() __attribute__((always_inline)) {
+        auto coef_loads = [&]() __attribute__((always_inline)) {
+            if (gstat) {
+                qn_g[0] = *(const f32x4*)(a.gs_gamma + q_cbs); qn_g[1] = *(const f32x4*)(a.gs_gamma + q_cbs + 4);
+                qn_bt[0] = *(const f32x4*)(a.gs_beta + q_cbs); qn_bt[1] = *(const f32x4*)(a.gs_beta + q_cbs + 4);
+            } else gkn.load(a.gn_ab + (size_t)q_b * a.Cin + q_cbs, gn && q_cv);
+        };
+        auto coef_sel = [&]() __attribute__((always_inline)) {
+            if (gstat) {
+                const int src = (q_cbs / a.gs_cpg) * 8;                    // a lane that holds the statistics of the channels' group
+                qn_mean = __shfl(st_mean, src); qn_rstd = __shfl(st_rstd, src);
+            }
+        };
+        auto prep = [&]() __attribute__((always_inline)) {
+            const bool fresh = decode();
+            coef_loads();
+            if (fresh) { stats_issue(q_b); stats_reduce(); st_b = q_b; }
+            coef_sel();
+        };
+        auto adopt = [&]() __attribute__((always_inline)) {
+            if (gstat) gk.from_raw(qn_g, qn_bt, qn_mean, qn_rstd, gn && q_cv_i);
+            else gk = gkn;
+        };
+        auto issue_loads = [&]() __attribute__((always_inline)) {
             // (readfirstlane: these are wave-uniform by construction; saying so keeps the descriptor in SGPRs)
             const int b = __builtin_amdgcn_readfirstlane(q_b), iy0 = __builtin_amdgcn_readfirstlane(q_iy0), ix0 = __builtin_amdgcn_readfirstlane(q_ix0);
             const int cc = __builtin_amdgcn_readfirstlane(S2 ? q_c / 5 : q_c);     // channel chunk
@@ -178,7 +246,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
             const int cb = cc * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
-            gk = gkn;
+            q_cv_i = cv;
             // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
             // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
             // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
@@ -205,7 +273,19 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
             }
         };
+        auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
         auto request = [&]() __attribute__((always_inline)) { prep(); issue(); };
+        // the kernel's first request: input loads go out BEFORE the wave waits for the partial sums (one memory round trip for
+        // everything the first dump needs instead of two)
+        auto request_first = [&]() __attribute__((always_inline)) {
+            const bool fresh = decode();
+            if (fresh) stats_issue(q_b);
+            coef_loads();
+            issue_loads();
+            if (fresh) { stats_reduce(); st_b = q_b; }
+            coef_sel();
+            adopt();
+        };
         auto dump = [&](int buf) __attribute__((always_inline)) {
             unsigned char* const As = smem + buf * L::A_BYTES;
             int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
@@ -238,6 +318,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
         f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
         int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0, e_kh = 0, e_tile = 0;
+        bool pd_on = false;                      // a tile's per-wave GroupNorm sums wait in LDS for combine()
+        int pd_b = 0, pd_slot = 0, pd_n0 = 0;
         unsigned char* const kpartb = (unsigned char*)a.kpart;
         unsigned e_base = 0;
         int e_rows = 0;                          // wave-uniform: valid rows of the tile
@@ -396,24 +478,35 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { chs[(lane * 8 + e) * 2] = s1[e]; chs[(lane * 8 + e) * 2 + 1] = s2[e]; }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS is in order per wave
-                const int n0 = e_nt * BN;
-                if (n0 < a.Cout) {
-                    const int nend = min(n0 + BN, a.Cout);
-                    const int g = n0 / a.cpg + lane;
-                    if (g <= (nend - 1) / a.cpg) {
-                        const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
-                        float t1 = 0.f, t2 = 0.f;
-                        for (int c = clo; c < chi; ++c) { t1 += chs[(c - n0) * 2]; t2 += chs[(c - n0) * 2 + 1]; }
-                        const int slot = (((e_ty * a.n_tx + e_tx) * a.npar + e_par) * 4 + pw) * a.n_nt + e_nt;
-                        part_store(a.part + (size_t)(e_b * a.G + g) * a.nslot + slot, t1, t2);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // sums consumed before the next epilogue rewrites them
+                // the four waves' per-channel sums are combined into ONE slot per tile after the next workgroup barrier (combine())
+                pd_on = true; pd_b = e_b; pd_n0 = e_nt * BN;
+                pd_slot = ((e_ty * a.n_tx + e_tx) * a.npar + e_par) * a.n_nt + e_nt;
+            }
+        };
+        // After the barrier that follows an epilogue: group sums over the four producer waves' per-channel sums, one slot per
+        // (tile, group) -- a quarter of the slots a per-wave publication needs, which is what lets the consuming conv reduce
+        // them itself in one round of loads (stats() above).  Wave pw takes every fourth group of the tile's channel range;
+        // fixed summation order (lane tree), so the statistics stay run-to-run deterministic.
+        auto combine = [&]() __attribute__((always_inline)) {
+            if (!pd_on) return;
+            pd_on = false;
+            const float* const all = (const float*)(stg + L::STG_BYTES);
+            const int n0 = pd_n0;
+            if (n0 >= a.Cout) return;
+            const int nend = min(n0 + BN, a.Cout);
+            const int g1 = (nend - 1) / a.cpg;
+            for (int g = n0 / a.cpg + pw; g <= g1; g += 4) {
+                const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
+                float t1 = 0.f, t2 = 0.f;
+                const float* const wa = all + (lane >> 4) * 256;
+                for (int c = clo + (lane & 15); c < chi; c += 16) { t1 += wa[(c - n0) * 2]; t2 += wa[(c - n0) * 2 + 1]; }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
+                if (lane == 0) part_store(a.part + (size_t)(pd_b * a.G + g) * a.nslot + pd_slot, t1, t2);
             }
         };
 
-        request();
+        request_first();
         dump(0);
         request();
         raw_barrier();                                             // chunk 0 visible
@@ -441,10 +534,16 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const bool early = k + 1 == ktotal && !(ks == 2 && e_kh == 1);
             if (early) epi_request();
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
+            combine();                                             // (the sums of an epilogue that ran in this iteration)
             if (++c == nck) { c = 0; ++ti; }
         }
         if (ks == 2 && e_kh == 1) epi_request();
         epilogue();                                                // last tile
+        if (pd_on) {
+            // the consumers have left (or are leaving) the kernel: a barrier now waits for the surviving waves only, i.e. the four producers
+            raw_barrier();
+            combine();
+        }
         stamp(2); stamp_cycles();
         return;
     }
@@ -459,6 +558,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         constexpr int WIN = 6, PF = 4;                             // row-fragment window / prefetch distance (rows)
         constexpr int DG = 3;                                      // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
         constexpr int NG = 12, NROW = HROWS;
+#ifdef CCN_WLOAD_AT0
+        constexpr bool WLOAD_AT0 = true;
+#else
+        constexpr bool WLOAD_AT0 = false;
+#endif
         static_assert((NG * NROW) % WIN == 0 && NG % DG == 0, "static ring indexing");
         f32x16 acc[TH];
         const int n32 = a.Cout_pad / 32;
@@ -513,12 +617,18 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 for (int s_ = 0; s_ < NG * NROW; ++s_) {
                     const int g = s_ / NROW, hh = s_ % NROW;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (hh == 0) {
-                        // refill the ring slot group g-1 released with the fragments of group g+DG-1 (wraps into the next chunk / tile)
+                    {
+                        // refill the ring slot group g-1 released with the fragments of group g+DG-1 (wraps into the next chunk / tile).
+                        // One 1-KiB load per step, in the steps that carry three MFMAs: a wave-wide 16-byte load holds the wave's
+                        // issue for tens of cycles, and all four consumer waves reach the same step together -- three loads in the
+                        // one-MFMA step hh = 0 (the round-1 placement, -DCCN_WLOAD_AT0=1) stalled the MFMA stream there
                         const int pg = g + DG - 1;
                         const unsigned off = pg < NG ? wb_cur + (unsigned)(pg * 3) * 1024u : wb_nxt + (unsigned)((pg - NG) * 3) * 1024u;
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) bq[pg % DG][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off + dy * 1024, 0);
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int lh = WLOAD_AT0 ? 0 : (TH == 8 ? 2 + 2 * dy : 2 + dy);
+                            if (hh == lh) bq[pg % DG][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off + dy * 1024, 0);
+                        }
                     }
                     if (s_ + PF < NG * NROW) rload(s_ + PF);
                     int nm = 0;
@@ -531,7 +641,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     for (int m = 0; m < 3; ++m) {
                         if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (hh == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (WLOAD_AT0 ? hh == 0 : (m == 1 && (TH == 8 ? (hh == 2 || hh == 4 || hh == 6) : (hh >= 2 && hh <= 4))))
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);

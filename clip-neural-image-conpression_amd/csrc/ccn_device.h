@@ -106,6 +106,15 @@ template <> struct GnCoef<__bf16> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[2 * e] = v[e][0]; a[2 * e + 1] = v[e][1]; c[2 * e] = v[e][2]; c[2 * e + 1] = v[e][3]; }
     }
+    // scale = gamma * rstd, shift = beta - mean * scale from raw affine parameters and a group's statistics
+    __device__ __forceinline__ void from_raw(const f32x4* g, const f32x4* bt, float mean, float rstd, bool valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = g[e >> 2][e & 3] * rstd;
+            a[e] = valid ? sc : 1.f;
+            c[e] = valid ? fmaf(-mean, sc, bt[e >> 2][e & 3]) : 0.f;
+        }
+    }
     template <bool SILU> __device__ __forceinline__ u32x4 apply(const u32x4& raw) const {
         const float nl2e = -1.4426950408889634f;
         u32x4 o;

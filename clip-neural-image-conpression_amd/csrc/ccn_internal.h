@@ -41,6 +41,11 @@ struct ConvArgs {
     const float* bias;      // [Cout]
     void* out;              // NHWC T [B][Hout][Wout][Cout] (head: unused)
     const float2* gn_ab;    // prologue GroupNorm: per sample C float2 slots, pair-interleaved {scale(2p), scale(2p+1), shift(2p), shift(2p+1)}, or null
+    // persistent kernel: the input GroupNorm's finalize done in-kernel from the producer's partial sums (gn_ab then null):
+    const float2* gs_part;  // [B][8][gs_nsp * gs_nnt] partial sums of the input tensor, or null
+    const float* gs_gamma; const float* gs_beta;   // [Cin]
+    double gs_inv_count;    // 1 / elements per (sample, group)
+    int gs_nsp, gs_nnt, gs_bn, gs_cpg;              // layout of the partial sums (as gn_finalize takes it), channels per group
     const float* film;      // epilogue FiLM for this step: [B][film_bstride], s at [n], shift at [Cout+n]; or null
     const void* res;        // epilogue residual / skip, NHWC T like out; or null
     float2* part;           // epilogue GroupNorm partial sums [B][G][nslot] (sum, sum of squares); or null

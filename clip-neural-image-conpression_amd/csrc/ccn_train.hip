@@ -355,7 +355,7 @@ struct Walk {
         a.nchunk = Kpad / cke;
         a.silu = 1; a.ksplit = 1;
         a.G = groups_for(N); a.cpg = N / a.G;
-        a.nslot = a.n_ty * a.n_tx * g.npar * n_nt * (pr ? 4 : 1);          // the persistent kernel publishes one partial per producer wave
+        a.nslot = a.n_ty * a.n_tx * g.npar * n_nt;                        // (the persistent kernel too: one partial per tile)
         a.film_bstride = tr->F;
         a.bn = BN;
         a.fin_blocks = a.n_ty * a.n_tx * g.npar * n_nt;
@@ -363,7 +363,7 @@ struct Walk {
         fill_taps(a.tapinfo, kind, four);
         if (want_part && out) {
             out->part = (float2*)take((size_t)B * a.G * a.nslot * sizeof(float2));
-            out->n_sp = a.n_ty * a.n_tx * g.npar * (pr ? 4 : 1); out->n_nt = n_nt; out->bn = BN;
+            out->n_sp = a.n_ty * a.n_tx * g.npar; out->n_nt = n_nt; out->bn = BN;
             a.part = out->part;
         }
         if (!launch) return true;
