@@ -81,37 +81,79 @@ def aggregate(rows: np.ndarray) -> dict:
     return res
 
 
+def default_workers(world: int) -> int:
+    """Host threads of one rank: this process's CPU share divided over the ranks of the node, 2..16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+    return max(2, min(16, n // max(world, 1)))
+
+
+def original_u8(path: str, size: int) -> np.ndarray:
+    """The uint8 image the reference's PSNR / SSIM see for an original: its float form ([-1, 1], cli/eval.py:66-67) pushed
+    through ``_to_uint8`` again (eval/metrics.py:16-19) -- NOT the decoded pixels: v / 127.5 - 1 + 1 does not round-trip in
+    fp32 and the truncation then loses a level on some values, which the reference's numbers include."""
+    from ..eval.metrics import _to_uint8
+    return _to_uint8(load_original(path, size))
+
+
+def metric_row_u8(orig_u8: np.ndarray, recon_u8: np.ndarray) -> List[float]:
+    from ..eval.metrics import psnr_u8, ssim_u8
+    return [psnr_u8(orig_u8, recon_u8), ssim_u8(orig_u8, recon_u8), float("nan"), float("nan")]
+
+
 def evaluate(manifest: List[dict], z_of: Callable[[dict], np.ndarray], reconstruct: Callable, size: int, batch: int,
              seed: Optional[int], rank: int, world: int, device: str, start_noise_fn: Callable, submit: Optional[Callable] = None,
-             fetch: Optional[Callable] = None) -> np.ndarray:
+             fetch: Optional[Callable] = None, workers: Optional[int] = None, u8: bool = False) -> np.ndarray:
     """Shard, reconstruct in batches, score on the host, gather.  ``reconstruct(z, x_T) -> (b,3,S,S)`` numpy in [-1,1].
 
     With ``submit(z, x_T, slot) -> handle`` / ``fetch(handle) -> numpy`` (the GPU path) two batches are kept in flight: batch k+1 is
     enqueued on the other stream before batch k's result is waited for -- consecutive batches are independent, and one batch's kernel
-    tails and launch gaps fill with the other's work (80 vs 71 images/s per GPU at C2)."""
+    tails and launch gaps fill with the other's work.  Everything the host does per record -- PNG decode + resize, the .clp read and z
+    decode, the per-record start noise, PSNR / SSIM -- runs on a pool of ``workers`` threads (numpy / scipy / PIL / torch release the
+    GIL in their kernels), inputs prepared one batch AHEAD of the GPU and metrics collected only at the end, so the submitting
+    thread never waits for host work.  ``u8``: ``fetch`` returns the reconstruction already converted to uint8 on the device
+    (a quarter of the D2H bytes; same arithmetic as ``_to_uint8``) and the originals are converted once."""
     mine = shard_indices(len(manifest), rank, world)
-    rows: List[List[float]] = []
-    with ThreadPoolExecutor(max_workers=4) as pool:
-        pending = None                                             # (handle, originals) of the batch still on the GPU
-        def finish(p):
-            recon = fetch(p[0])
-            futs = [pool.submit(metric_row, o.result(), recon[k], device) for k, o in enumerate(p[1])]
-            return [f.result() for f in futs]
-        for bi, lo in enumerate(range(0, len(mine), batch)):
-            idx = mine[lo:lo + batch]
-            originals = [pool.submit(load_original, manifest[i]["image"], size) for i in idx]
-            z = np.concatenate([z_of(manifest[i]) for i in idx], 0)
+    nw = workers or default_workers(world)
+    batches = [mine[lo:lo + batch] for lo in range(0, len(mine), batch)]
+    rows_f: List = []                                              # one future per record, in `mine` order
+
+    with ThreadPoolExecutor(max_workers=nw) as pool:
+        def prepare(idx):
+            """Futures of one batch's inputs: originals (float or uint8), z rows, start-noise rows (None when unseeded)."""
+            load = original_u8 if u8 else load_original
+            return dict(idx=idx,
+                        orig=[pool.submit(load, manifest[i]["image"], size) for i in idx],
+                        z=[pool.submit(z_of, manifest[i]) for i in idx],
+                        noise=None if seed is None else [pool.submit(start_noise_fn, [i], size, seed) for i in idx])
+
+        def inputs(p):
+            z = np.concatenate([f.result() for f in p["z"]], 0)
+            x_T = None if p["noise"] is None else torch.cat([f.result() for f in p["noise"]], 0)
+            return z, x_T
+
+        def score(p, recon):
+            for k, o in enumerate(p["orig"]):
+                if u8:
+                    rows_f.append(pool.submit(lambda of, r: metric_row_u8(of.result(), r), o, recon[k]))
+                else:
+                    rows_f.append(pool.submit(lambda of, r: metric_row(of.result(), r, device), o, recon[k]))
+
+        ahead = prepare(batches[0]) if batches else None
+        pending = None                                             # (handle, prepared batch) still on the GPU
+        for bi in range(len(batches)):
+            cur = ahead
+            ahead = prepare(batches[bi + 1]) if bi + 1 < len(batches) else None
+            z, x_T = inputs(cur)
             if submit is not None and fetch is not None:
-                handle = submit(z, start_noise_fn(idx, size, seed), bi & 1)
+                handle = submit(z, x_T, bi & 1)
                 if pending is not None:
-                    rows += finish(pending)
-                pending = (handle, originals)
-                continue
-            recon = reconstruct(z, start_noise_fn(idx, size, seed))
-            futs = [pool.submit(metric_row, o.result(), recon[k], device) for k, o in enumerate(originals)]
-            rows += [f.result() for f in futs]
+                    score(pending[1], fetch(pending[0]))
+                pending = (handle, cur)
+            else:
+                score(cur, reconstruct(z, x_T))
         if pending is not None:
-            rows += finish(pending)
+            score(pending[1], fetch(pending[0]))
+        rows = [f.result() for f in rows_f]
     local = np.asarray(rows, dtype=np.float64).reshape(len(mine), len(METRIC_KEYS))
     return gather_metric_rows(mine, local, len(manifest), device)
 
@@ -128,6 +170,8 @@ def main(argv=None) -> None:
     ap.add_argument("--batch", type=int, default=8, help="records per fused DDIM launch per GPU")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--timing", action="store_true", help="print set-up and loop wall time (records/s of the loop) to stderr")
+    ap.add_argument("--workers", type=int, default=None, help="host threads for decode / metrics (default: this rank's share of the CPUs, 2..16)")
     ap.add_argument("--gpus", type=int, default=None,
                     help="shard the store over this many GPUs of the node: one process per GPU is started here unless a launcher "
                          "(torchrun) already did; default: the launcher's WORLD_SIZE, else 1")
@@ -146,6 +190,9 @@ def main(argv=None) -> None:
     if world > 1:
         init_process_group(device)                                 # RCCL; CCN_DIST_BACKEND=gloo for several ranks on one card
 
+    import sys
+    import time
+    t_start = time.perf_counter()
     store_dir = Path(args.store_dir)
     manifest = json.loads((store_dir / "manifest.json").read_text(encoding="utf-8"))
     scale, zero = load_codec_meta(store_dir)
@@ -160,6 +207,13 @@ def main(argv=None) -> None:
         return x.clamp(-1, 1).cpu().numpy()
 
     streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    pinned: dict = {}
+    # parallelism on the host comes from the worker threads; torch's own intra-op pool only gets in their way (a 196k-element
+    # randn went from 1 to 60 ms per record when eight threads fought over it)
+    torch.set_num_threads(1)
+    from ..eval.metrics import learned_metrics_available
+    # LPIPS / CLIP similarity need the float images (and packages that are absent offline); without them only uint8 leaves the GPU
+    u8 = not learned_metrics_available()
 
     def submit(z: np.ndarray, x_T: Optional[torch.Tensor], slot: int):
         zt = torch.from_numpy(z).to(device)
@@ -168,17 +222,31 @@ def main(argv=None) -> None:
         st.wait_stream(torch.cuda.current_stream(device))
         with torch.no_grad(), torch.cuda.stream(st):
             x = sampler.sample(net, zt, shape=(zt.shape[0], 3, args.size, args.size), steps=args.steps, x_T=xt, slot=slot).clamp(-1, 1)
+            if u8:
+                # _to_uint8 (eval/metrics.py:16-19) on the device: the same two separately rounded fp32 ops, clip, truncation
+                x = ((x + 1.0) * 127.5).clamp(0, 255).to(torch.uint8)
+            key = (slot, tuple(x.shape), x.dtype)
+            host = pinned.get(key)
+            if host is None:
+                host = pinned[key] = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+            host.copy_(x, non_blocking=True)
         ev = torch.cuda.Event(); ev.record(st)
-        return x, ev, zt, xt                                       # inputs kept alive until the result is fetched
+        return host, ev, zt, xt, x                                 # device tensors kept alive until the result is fetched
 
     def fetch(handle) -> np.ndarray:
         handle[1].synchronize()
-        return handle[0].cpu().numpy()
+        net.native().poll_errors()                                 # a device-side failure flagged during this batch raises here
+        return handle[0].numpy().copy()                            # the pinned buffer of this slot is reused two batches later
 
     pipelined = args.eta == 0                                      # the fused sampler; eta > 0 draws noise step by step
+    t_loop = time.perf_counter()
     rows = evaluate(manifest, lambda rec: load_embedding(Path(rec["bitstream"]), scale, zero), reconstruct,
                     args.size, args.batch, args.seed, rank, world, device, start_noise,
-                    submit if pipelined else None, fetch if pipelined else None)
+                    submit if pipelined else None, fetch if pipelined else None, workers=args.workers, u8=u8 and pipelined)
+    if args.timing and rank == 0:
+        t_end = time.perf_counter()
+        print(f"[eval] set-up {t_loop - t_start:.2f} s (checkpoint load + weight repack), loop {t_end - t_loop:.2f} s for {len(manifest)} records = "
+              f"{len(manifest) / (t_end - t_loop):.1f} records/s over {world} rank(s) (first batch includes plan + graph capture)", file=sys.stderr)
     if rank == 0:
         agg = aggregate(rows)
         print(f"Average PSNR: {agg['psnr']:.2f} dB")

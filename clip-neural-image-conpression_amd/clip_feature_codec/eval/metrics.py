@@ -19,12 +19,17 @@ def _to_uint8(img: np.ndarray) -> np.ndarray:
     return ((img + 1.0) * 127.5).clip(0, 255).astype(np.uint8)
 
 
-def psnr(img1: np.ndarray, img2: np.ndarray) -> float:
-    d = _to_uint8(img1).astype(np.float32) - _to_uint8(img2).astype(np.float32)
+def psnr_u8(x1: np.ndarray, x2: np.ndarray) -> float:
+    """PSNR of two uint8 images -- what ``psnr`` computes after its uint8 conversion (eval/metrics.py:22-29)."""
+    d = x1.astype(np.float32) - x2.astype(np.float32)
     mse = np.mean(d ** 2)
     if mse == 0:
         return float("inf")
     return 20.0 * np.log10(255.0 / np.sqrt(mse))
+
+
+def psnr(img1: np.ndarray, img2: np.ndarray) -> float:
+    return psnr_u8(_to_uint8(img1), _to_uint8(img2))
 
 
 def _ssim_plane(a: np.ndarray, b: np.ndarray, data_range: float = 255.0, win: int = 7) -> float:
@@ -42,7 +47,11 @@ def _ssim_plane(a: np.ndarray, b: np.ndarray, data_range: float = 255.0, win: in
 
 
 def ssim(img1: np.ndarray, img2: np.ndarray) -> float:
-    x1, x2 = _to_uint8(img1), _to_uint8(img2)
+    return ssim_u8(_to_uint8(img1), _to_uint8(img2))
+
+
+def ssim_u8(x1: np.ndarray, x2: np.ndarray) -> float:
+    """SSIM of two uint8 images (CHW or HWC) -- the part of ``ssim`` after its uint8 conversion."""
     if x1.ndim == 3 and x1.shape[0] in (1, 3):
         x1, x2 = x1.transpose(1, 2, 0), x2.transpose(1, 2, 0)
     try:
@@ -57,6 +66,17 @@ def ssim(img1: np.ndarray, img2: np.ndarray) -> float:
         return float(np.mean([_ssim_plane(x1[..., c], x2[..., c]) for c in range(x1.shape[2])]))
     except Exception:
         return float("nan")
+
+
+def learned_metrics_available() -> bool:
+    """True if LPIPS or CLIP similarity could produce a number here (their packages import); offline both are NaN."""
+    for mod in ("lpips", "open_clip"):
+        try:
+            __import__(mod)
+            return True
+        except Exception:
+            pass
+    return False
 
 
 def lpips_distance(img1: np.ndarray, img2: np.ndarray, device: str = "cpu") -> float:

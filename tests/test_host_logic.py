@@ -163,3 +163,25 @@ def test_training_forward_refuses_cpu_tensors(tiny_sd):
     net = CLIPCondUNet(base=32, ch_mult=(1, 2)).train()
     with pytest.raises(RuntimeError, match="HIP device"):
         net(torch.zeros(1, 3, 32, 32), torch.zeros(1, 512), torch.zeros(1, dtype=torch.long))
+
+
+def test_uint8_metric_path_equals_the_float_path(tmp_path):
+    """cli.eval moves uint8 off the GPU and scores uint8 images: the conversion is the reference's ``_to_uint8`` (two separately
+    rounded fp32 ops, clip, truncation; eval/metrics.py:16-19) done with torch ops, and the originals go through the same float
+    round trip the reference applies to them -- PSNR and SSIM must equal the float-array route bit for bit."""
+    import torch
+    from PIL import Image
+    from clip_feature_codec.cli import eval as cli_eval
+    from clip_feature_codec.eval import metrics
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)
+    path = tmp_path / "o.png"
+    Image.fromarray(img).save(path)
+    recon = torch.from_numpy(rng.uniform(-1.3, 1.3, (3, 48, 48)).astype(np.float32)).clamp(-1, 1)
+    orig_f = cli_eval.load_original(str(path), 48)
+    want = [metrics.psnr(orig_f, recon.numpy()), metrics.ssim(orig_f, recon.numpy())]
+    recon_u8 = ((recon + 1.0) * 127.5).clamp(0, 255).to(torch.uint8).numpy()
+    assert np.array_equal(recon_u8, metrics._to_uint8(recon.numpy()))
+    got = cli_eval.metric_row_u8(cli_eval.original_u8(str(path), 48), recon_u8)
+    assert got[0] == want[0] and got[1] == want[1] and np.isnan(got[2]) and np.isnan(got[3])
+    assert 2 <= cli_eval.default_workers(1) <= 16 and cli_eval.default_workers(64) == 2

@@ -19,7 +19,7 @@ from clip_feature_codec.utils import synth  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=256); ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--n", type=int, default=256); ap.add_argument("--size", type=int, default=256); ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as d:
         d = Path(d)
@@ -27,7 +27,7 @@ def main():
         sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
         torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, d / "ckpt.pt")
         argv = ["--store_dir", str(d), "--weights", str(d / "ckpt.pt"), "--size", str(a.size), "--steps", "50", "--batch", "8", "--seed", "1",
-                "--device", "cuda", "--dtype", a.dtype, "--out_json", str(d / "m.json")]
+                "--device", "cuda", "--dtype", a.dtype, "--out_json", str(d / "m.json"), "--timing"]
         for it in range(2):                                   # first pass pays checkpoint repack + graph capture
             buf = io.StringIO()
             torch.cuda.synchronize(); t0 = time.perf_counter()
