@@ -102,7 +102,7 @@ def metric_row_u8(orig_u8: np.ndarray, recon_u8: np.ndarray) -> List[float]:
 
 def evaluate(manifest: List[dict], z_of: Callable[[dict], np.ndarray], reconstruct: Callable, size: int, batch: int,
              seed: Optional[int], rank: int, world: int, device: str, start_noise_fn: Callable, submit: Optional[Callable] = None,
-             fetch: Optional[Callable] = None, workers: Optional[int] = None, u8: bool = False) -> np.ndarray:
+             fetch: Optional[Callable] = None, workers: Optional[int] = None, u8: bool = False, marks: Optional[list] = None) -> np.ndarray:
     """Shard, reconstruct in batches, score on the host, gather.  ``reconstruct(z, x_T) -> (b,3,S,S)`` numpy in [-1,1].
 
     With ``submit(z, x_T, slot) -> handle`` / ``fetch(handle) -> numpy`` (the GPU path) two batches are kept in flight: batch k+1 is
@@ -144,6 +144,9 @@ def evaluate(manifest: List[dict], z_of: Callable[[dict], np.ndarray], reconstru
             cur = ahead
             ahead = prepare(batches[bi + 1]) if bi + 1 < len(batches) else None
             z, x_T = inputs(cur)
+            if marks is not None:
+                import time
+                marks.append((time.perf_counter(), sum(len(b) for b in batches[:bi])))   # (when batch bi is handed over, records before it)
             if submit is not None and fetch is not None:
                 handle = submit(z, x_T, bi & 1)
                 if pending is not None:
@@ -240,13 +243,18 @@ def main(argv=None) -> None:
 
     pipelined = args.eta == 0                                      # the fused sampler; eta > 0 draws noise step by step
     t_loop = time.perf_counter()
+    marks: list = []
     rows = evaluate(manifest, lambda rec: load_embedding(Path(rec["bitstream"]), scale, zero), reconstruct,
                     args.size, args.batch, args.seed, rank, world, device, start_noise,
-                    submit if pipelined else None, fetch if pipelined else None, workers=args.workers, u8=u8 and pipelined)
+                    submit if pipelined else None, fetch if pipelined else None, workers=args.workers, u8=u8 and pipelined,
+                    marks=marks)
     if args.timing and rank == 0:
         t_end = time.perf_counter()
         print(f"[eval] set-up {t_loop - t_start:.2f} s (checkpoint load + weight repack), loop {t_end - t_loop:.2f} s for {len(manifest)} records = "
-              f"{len(manifest) / (t_end - t_loop):.1f} records/s over {world} rank(s) (first batch includes plan + graph capture)", file=sys.stderr)
+              f"{len(manifest) / (t_end - t_loop):.1f} records/s over {world} rank(s) (the first two batches include plan + graph capture)", file=sys.stderr)
+        if len(marks) > 3:                                         # this rank's steady state: from the hand-over of its third batch on
+            n_rank = len(shard_indices(len(manifest), rank, world))
+            print(f"[eval] steady state of rank 0: {(n_rank - marks[2][1]) / (t_end - marks[2][0]):.1f} records/s per rank", file=sys.stderr)
     if rank == 0:
         agg = aggregate(rows)
         print(f"Average PSNR: {agg['psnr']:.2f} dB")
