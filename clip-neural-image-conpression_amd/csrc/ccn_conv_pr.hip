@@ -132,6 +132,229 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
     stamp(0);
 
+    // ---- epilogue machinery (role-neutral: the producers run it for every tile, and the consumers join them for the LAST tile of
+    // the launch, whose epilogue nothing overlaps).  thread -> fixed channel octet o16 of the tile's 128, pixels pr + 16*it
+    // (it < 2 TH) of its 32 TH: row it>>1, column pr + 16*(it&1); residual rows, bias and FiLM are fetched during the tile's last chunk
+    const int etid = tid & 255, ew = wave & 3;
+    const int o16 = etid & 15, pr = etid >> 4;
+    unsigned char* const outb = (unsigned char*)a.out;
+    const unsigned char* const resb = (const unsigned char*)a.res;
+    const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
+    // per-wave channel sums of an epilogue: producer waves behind the staging tile; consumer waves (last tile only) at the start
+    // of the input buffers, which nobody touches after the final barrier of the chunk loop
+    float* const chs = (float*)(wave >= 4 ? stg + L::STG_BYTES : smem) + ew * 256;
+    constexpr int NQ = TH / 2;               // epilogue batches of 4 items (two tile rows each)
+    u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
+    f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
+    int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0, e_kh = 0, e_tile = 0;
+    bool pd_on = false;                      // a tile's per-wave GroupNorm sums wait in LDS for combine()
+    int pd_b = 0, pd_slot = 0, pd_n0 = 0;
+    unsigned char* const kpartb = (unsigned char*)a.kpart;
+    unsigned e_base = 0;
+    int e_rows = 0;                          // wave-uniform: valid rows of the tile
+    unsigned e_m0 = OOB, e_m1 = OOB;         // 0 when this thread's first / second column (and its octet) is inside the tensor
+    // byte offset of item it (row it>>1, column pr + 16*(it&1)); masked-out items land past num_records.  Callers pass a
+    // laundered copy of e_base: otherwise the 16 offsets are computed once per tile and kept live across dump() and the barrier
+    auto item_off = [&](unsigned eb, int it) __attribute__((always_inline)) -> unsigned {
+        const unsigned rmask = (it >> 1) < e_rows ? 0u : OOB;                 // wave-uniform
+        return (eb + (unsigned)(it >> 1) * (unsigned)(a.OS * a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.OS * a.Cout * (int)sizeof(T)))
+               | ((it & 1) ? e_m1 : e_m0) | rmask;
+    };
+    // during the tile's last chunk: decode the tile
+    auto epi_setup = [&](int v) __attribute__((always_inline)) {
+        const int tile = vt_tile(v);
+        e_kh = vt_kh(v); e_tile = tile;
+        e_nt = tile % a.n_nt;
+        const int t2 = tile / a.n_nt;
+        e_par = t2 % a.npar;
+        const int sp = t2 / a.npar;
+        e_tx = sp % a.n_tx; e_ty = (sp / a.n_tx) % a.n_ty; e_b = sp / (a.n_tx * a.n_ty);
+        const int nb = e_nt * BN + o16 * 8;
+        const bool nvalid = nb < a.Cout;
+        // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
+        e_base = (unsigned)(((e_b * a.Hout + e_ty * TH * a.OS + (e_par >> 1)) * a.Wout + (e_tx * 32 + pr) * a.OS + (e_par & 1)) * a.Cout + nb) * (unsigned)sizeof(T);
+        e_rows = a.MH - e_ty * TH;
+        e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
+        e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
+    };
+    // residual source of the current epilogue: the residual tensor, or (second K half) the first half's partial tile
+    auto res_on = [&]() __attribute__((always_inline)) -> bool { return RES || (MODE == 2 && ks == 2 && e_kh == 1); };
+    auto res_batch = [&](int q, u32x4* dst) __attribute__((always_inline)) {
+        if constexpr (RR) {
+            if (res_on()) {
+                const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)((ks == 2 && e_kh == 1) ? kpartb : (resb ? resb : outb)), 0, out_bytes, 0x00020000);
+                unsigned eb = e_base; asm volatile("" : "+v"(eb));
+                if (ks == 2 && e_kh == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 1);   // sc0: bypass L1
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt (experiment)
+                        else dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    // start of the epilogue iteration: bias / FiLM (raw: folding them here would wait for the loads) and the first two
+    // residual batches; all of it flies during request()
+    auto epi_request = [&](int q0, int q1) __attribute__((always_inline)) {
+        if (ks == 2 && e_kh == 1) {
+            // second K half: the partner's partial tile must be complete.  Thread t reads exactly what thread t of the partner
+            // wrote, so one flag per producer wave is enough.  Bounded spin: a protocol bug must not hang the GPU.
+            unsigned* const fl = a.kflag + (size_t)e_tile * 4 + ew;
+            if (lane == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                // the partner never arrived (it cannot happen while both halves are co-resident, which launch_conv_pr
+                // guarantees): the tile below is then wrong -- say so in the handle's error word, which the next API call
+                // (or ccn_poll_errors) turns into CCN_EHIP, instead of falling through silently
+                if (spins >= (1 << 22) && a.err) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+            // No agent-scope acquire fence here (it would invalidate the XCD's whole L2): the partner workgroup runs on the
+            // same XCD -- partners are virtual tiles 2t, 2t+1 and launch_conv_pr makes the split-K grid a multiple of 16, so
+            // that every XCD's contiguous range [x*grid/8, (x+1)*grid/8) starts at an even id and holds whole pairs -- its
+            // stores are write-through to that L2, and this CU cannot hold stale lines of the partial tensor (L1 is
+            // invalidated at kernel start and the lines are read for the first time now, with the L1-bypass bit set).
+            asm volatile("" ::: "memory");
+        }
+        const int nb = e_nt * BN + o16 * 8;
+        const int nbs = nb < a.Cout ? nb : 0;
+        fb[0] = *(const f32x4*)(a.bias + nbs); fb[1] = *(const f32x4*)(a.bias + nbs + 4);
+        if constexpr (!RES) {
+            if (a.film) {
+                const float* fp = a.film + (size_t)e_b * a.film_bstride;
+                fs[0] = *(const f32x4*)(fp + nbs); fs[1] = *(const f32x4*)(fp + nbs + 4);
+                ft[0] = *(const f32x4*)(fp + a.Cout + nbs); ft[1] = *(const f32x4*)(fp + a.Cout + nbs + 4);
+            }
+        }
+        res_batch(q0, rr[q0 & 1]);
+        if constexpr (RR) { if (q0 + 1 < q1) res_batch(q0 + 1, rr[(q0 + 1) & 1]); }
+    };
+    // the staging tile of the tile described by e_* is complete (the consumers wrote it before the last barrier)
+    // items of batches [q0, q1) (call sites pass constants: the loop below unrolls and folds)
+    auto epilogue = [&](int q0, int q1) __attribute__((always_inline)) {
+        // scalar fp32 math only (packed-fp32 ops starve next to the consumers' MFMA stream, see GnCoef), and the running
+        // sums pinned per item: left alone the compiler sums ACROSS the 16 unrolled items at the end and keeps all 128
+        // output values alive until then
+        const bool first = ks == 2 && e_kh == 0, second = ks == 2 && e_kh == 1;
+        // the first K half carries bias / FiLM shift / residual; the second only scales by the FiLM factor and adds the partial
+        float f1[RES ? 1 : 8], f2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f2[e] = second ? 0.f : fb[e >> 2][e & 3];
+            if constexpr (!RES) {
+                f1[e] = 1.f;
+                if (a.film) { f1[e] = 1.0f + fs[e >> 2][e & 3]; f2[e] = second ? 0.f : fmaf(f2[e], f1[e], ft[e >> 2][e & 3]); }
+            }
+        }
+        const auto osrd_c = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? kpartb : outb), 0, out_bytes, 0x00020000);
+        const bool radd = res_on();
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q < q0 || q >= q1) continue;
+            unsigned eb = e_base; asm volatile("" : "+v"(eb));
+            int sbase = pr * L::SP + o16 * 16; asm volatile("" : "+v"(sbase));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int it = q * 4 + i;
+                const unsigned off = item_off(eb, it);
+                const u32x4 sv = *(const u32x4*)(stg + sbase + ((it >> 1) * 32 + (it & 1) * 16) * L::SP);
+                const bool live = off < OOB;                          // masked items contribute nothing to the statistics
+                float x[8];
+                Vec16<T>::unpack(sv, x);
+                if constexpr (RES) {
+                    float rv[8];
+                    Vec16<T>::unpack(rr[q & 1][i], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = (x[e] + f2[e]) + rv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], f1[e], f2[e]);
+                    if constexpr (MODE == 2) {
+                        if (radd) {
+                            float rv[8];
+                            Vec16<T>::unpack(rr[q & 1][i], rv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += rv[e];
+                        }
+                    }
+                }
+                // Output stores are write-through (sc1): nothing is left dirty in the XCDs' L2s for the end-of-kernel release to
+                // write back before the next, dependent launch may start -- that flush cost every conv of a C2 forward 1.4-5 us
+                // (dirty bytes / ~6 TB/s): 74.3 -> 75.8 images/s; nt measured 75.4.  The split-K partial tile keeps plain stores
+                // (its reader is the partner workgroup on the same XCD, through that L2).  CCN_DBG=2048: plain stores (A/B).
+                if (first || CCN_DBG_BIT(a, 2048)) __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 16);
+                if (live) {                                           // exec-masked: costs scalar ops, not 8 VALU multiplies
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
+                }
+                asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
+                asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (RR) { if (q + 2 < q1) res_batch(q + 2, rr[q & 1]); }   // refill the buffer just consumed, one batch ahead
+        }
+        if (first) {
+            // publish the partial tile: every store of this wave visible at agent scope, then its flag
+            // (stores are write-through to the XCD's L2; waiting for their acknowledgement is the release -- an agent-scope
+            // release fence would write back the whole L2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(a.kflag + (size_t)e_tile * 4 + ew, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.part && !first) {
+#pragma unroll
+            for (int s = 16; s < 64; s <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], s); s2[e] += __shfl_xor(s2[e], s); }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { chs[(lane * 8 + e) * 2] = s1[e]; chs[(lane * 8 + e) * 2 + 1] = s2[e]; }
+            }
+            // the four waves' per-channel sums are combined into ONE slot per tile after the next workgroup barrier (combine())
+            pd_on = true; pd_b = e_b; pd_n0 = e_nt * BN;
+            pd_slot = ((e_ty * a.n_tx + e_tx) * a.npar + e_par) * a.n_nt + e_nt;
+        }
+    };
+    // After the barrier that follows an epilogue: group sums over the four producer waves' per-channel sums, one slot per
+    // (tile, group) -- a quarter of the slots a per-wave publication needs, which is what lets the consuming conv reduce
+    // them itself in one round of loads (stats()).  Wave ew takes every fourth group of the tile's channel range;
+    // fixed summation order (lane tree), so the statistics stay run-to-run deterministic.
+    // `areas` = 4, or 8 for the last tile when the consumer waves took half of its epilogue.
+    auto combine = [&](int areas) __attribute__((always_inline)) {
+        if (!pd_on) return;
+        pd_on = false;
+        const float* const all = (const float*)(stg + L::STG_BYTES);
+        const int n0 = pd_n0;
+        if (n0 >= a.Cout) return;
+        const int nend = min(n0 + BN, a.Cout);
+        const int g1 = (nend - 1) / a.cpg;
+        for (int g = n0 / a.cpg + ew; g <= g1; g += 4) {
+            const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
+            float t1 = 0.f, t2 = 0.f;
+            const float* const wa = all + (lane >> 4) * 256;
+            const float* const wc = (const float*)smem + (lane >> 4) * 256;
+            for (int c = clo + (lane & 15); c < chi; c += 16) {
+                t1 += wa[(c - n0) * 2]; t2 += wa[(c - n0) * 2 + 1];
+                if (areas == 8) { t1 += wc[(c - n0) * 2]; t2 += wc[(c - n0) * 2 + 1]; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
+            if (lane == 0) part_store(a.part + (size_t)(pd_b * a.G + g) * a.nslot + pd_slot, t1, t2);
+        }
+    };
+
+    // The last tile of the launch: its epilogue overlaps nothing (the consumers are done), so both roles run half of it each --
+    // producers the first TH/2 rows, consumers the rest -- and meet at one more barrier for the statistics.  Not under split-K
+    // (its hand-off flags are per producer wave).
+    const bool coop_tail = ks == 1 && !CCN_DBG_BIT(a, 1024);
+
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers (4 waves): input chunks + tile epilogues
         // The VALU is the scarce resource here (GroupNorm + SiLU costs ~45 VALU per 16 bytes, a quarter of them
@@ -265,7 +488,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > HROWS ? HROWS : (r_hi < 0 ? 0 : r_hi);
             rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
 #pragma unroll
-            for (int i = 0; i < HROWS; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
+            for (int i = 0; i < HROWS; ++i) {
+                if (CCN_DBG_BIT(a, 8192)) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 2);   // nt (experiment)
+                else areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
+            }
             {
                 const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
                 xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
@@ -307,205 +533,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             }
         };
 
-        // ---- epilogue: thread -> fixed channel octet o16 of the tile's 128, pixels pr + 16*it (it < 16) of its 256:
-        // row it>>1, column pr + 16*(it&1); residual rows, bias and FiLM are fetched during the tile's last chunk
-        const int o16 = ptid & 15, pr = ptid >> 4;
-        unsigned char* const outb = (unsigned char*)a.out;
-        const unsigned char* const resb = (const unsigned char*)a.res;
-        const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
-        float* const chs = (float*)(stg + L::STG_BYTES) + pw * 256;
-        constexpr int NQ = TH / 2;               // epilogue batches of 4 items (two tile rows each)
-        u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
-        f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
-        int e_b = 0, e_ty = 0, e_tx = 0, e_nt = 0, e_par = 0, e_kh = 0, e_tile = 0;
-        bool pd_on = false;                      // a tile's per-wave GroupNorm sums wait in LDS for combine()
-        int pd_b = 0, pd_slot = 0, pd_n0 = 0;
-        unsigned char* const kpartb = (unsigned char*)a.kpart;
-        unsigned e_base = 0;
-        int e_rows = 0;                          // wave-uniform: valid rows of the tile
-        unsigned e_m0 = OOB, e_m1 = OOB;         // 0 when this thread's first / second column (and its octet) is inside the tensor
-        // byte offset of item it (row it>>1, column pr + 16*(it&1)); masked-out items land past num_records.  Callers pass a
-        // laundered copy of e_base: otherwise the 16 offsets are computed once per tile and kept live across dump() and the barrier
-        auto item_off = [&](unsigned eb, int it) __attribute__((always_inline)) -> unsigned {
-            const unsigned rmask = (it >> 1) < e_rows ? 0u : OOB;                 // wave-uniform
-            return (eb + (unsigned)(it >> 1) * (unsigned)(a.OS * a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.OS * a.Cout * (int)sizeof(T)))
-                   | ((it & 1) ? e_m1 : e_m0) | rmask;
-        };
-        // during the tile's last chunk: decode the tile
-        auto epi_setup = [&](int v) __attribute__((always_inline)) {
-            const int tile = vt_tile(v);
-            e_kh = vt_kh(v); e_tile = tile;
-            e_nt = tile % a.n_nt;
-            const int t2 = tile / a.n_nt;
-            e_par = t2 % a.npar;
-            const int sp = t2 / a.npar;
-            e_tx = sp % a.n_tx; e_ty = (sp / a.n_tx) % a.n_ty; e_b = sp / (a.n_tx * a.n_ty);
-            const int nb = e_nt * BN + o16 * 8;
-            const bool nvalid = nb < a.Cout;
-            // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
-            e_base = (unsigned)(((e_b * a.Hout + e_ty * TH * a.OS + (e_par >> 1)) * a.Wout + (e_tx * 32 + pr) * a.OS + (e_par & 1)) * a.Cout + nb) * (unsigned)sizeof(T);
-            e_rows = a.MH - e_ty * TH;
-            e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
-            e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
-        };
-        // residual source of the current epilogue: the residual tensor, or (second K half) the first half's partial tile
-        auto res_on = [&]() __attribute__((always_inline)) -> bool { return RES || (MODE == 2 && ks == 2 && e_kh == 1); };
-        auto res_batch = [&](int q, u32x4* dst) __attribute__((always_inline)) {
-            if constexpr (RR) {
-                if (res_on()) {
-                    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)((ks == 2 && e_kh == 1) ? kpartb : (resb ? resb : outb)), 0, out_bytes, 0x00020000);
-                    unsigned eb = e_base; asm volatile("" : "+v"(eb));
-                    if (ks == 2 && e_kh == 1) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 1);   // sc0: bypass L1
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
-                    }
-                }
-            }
-        };
-        // start of the epilogue iteration: bias / FiLM (raw: folding them here would wait for the loads) and the first two
-        // residual batches; all of it flies during request()
-        auto epi_request = [&]() __attribute__((always_inline)) {
-            if (ks == 2 && e_kh == 1) {
-                // second K half: the partner's partial tile must be complete.  Thread t reads exactly what thread t of the partner
-                // wrote, so one flag per producer wave is enough.  Bounded spin: a protocol bug must not hang the GPU.
-                unsigned* const fl = a.kflag + (size_t)e_tile * 4 + pw;
-                if (lane == 0) {
-                    int spins = 0;
-                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-                    // the partner never arrived (it cannot happen while both halves are co-resident, which launch_conv_pr
-                    // guarantees): the tile below is then wrong -- say so in the handle's error word, which the next API call
-                    // (or ccn_poll_errors) turns into CCN_EHIP, instead of falling through silently
-                    if (spins >= (1 << 22) && a.err) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-                }
-                // No agent-scope acquire fence here (it would invalidate the XCD's whole L2): the partner workgroup runs on the
-                // same XCD -- partners are virtual tiles 2t, 2t+1 and launch_conv_pr makes the split-K grid a multiple of 16, so
-                // that every XCD's contiguous range [x*grid/8, (x+1)*grid/8) starts at an even id and holds whole pairs -- its
-                // stores are write-through to that L2, and this CU cannot hold stale lines of the partial tensor (L1 is
-                // invalidated at kernel start and the lines are read for the first time now, with the L1-bypass bit set).
-                asm volatile("" ::: "memory");
-            }
-            const int nb = e_nt * BN + o16 * 8;
-            const int nbs = nb < a.Cout ? nb : 0;
-            fb[0] = *(const f32x4*)(a.bias + nbs); fb[1] = *(const f32x4*)(a.bias + nbs + 4);
-            if constexpr (!RES) {
-                if (a.film) {
-                    const float* fp = a.film + (size_t)e_b * a.film_bstride;
-                    fs[0] = *(const f32x4*)(fp + nbs); fs[1] = *(const f32x4*)(fp + nbs + 4);
-                    ft[0] = *(const f32x4*)(fp + a.Cout + nbs); ft[1] = *(const f32x4*)(fp + a.Cout + nbs + 4);
-                }
-            }
-            res_batch(0, rr[0]);
-            if constexpr (RR) res_batch(1, rr[1]);
-        };
-        // the staging tile of the tile described by e_* is complete (the consumers wrote it before the last barrier)
-        auto epilogue = [&]() __attribute__((always_inline)) {
-            // scalar fp32 math only (packed-fp32 ops starve next to the consumers' MFMA stream, see GnCoef), and the running
-            // sums pinned per item: left alone the compiler sums ACROSS the 16 unrolled items at the end and keeps all 128
-            // output values alive until then
-            const bool first = ks == 2 && e_kh == 0, second = ks == 2 && e_kh == 1;
-            // the first K half carries bias / FiLM shift / residual; the second only scales by the FiLM factor and adds the partial
-            float f1[RES ? 1 : 8], f2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f2[e] = second ? 0.f : fb[e >> 2][e & 3];
-                if constexpr (!RES) {
-                    f1[e] = 1.f;
-                    if (a.film) { f1[e] = 1.0f + fs[e >> 2][e & 3]; f2[e] = second ? 0.f : fmaf(f2[e], f1[e], ft[e >> 2][e & 3]); }
-                }
-            }
-            const auto osrd_c = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? kpartb : outb), 0, out_bytes, 0x00020000);
-            const bool radd = res_on();
-            float s1[8], s2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                unsigned eb = e_base; asm volatile("" : "+v"(eb));
-                int sbase = pr * L::SP + o16 * 16; asm volatile("" : "+v"(sbase));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int it = q * 4 + i;
-                    const unsigned off = item_off(eb, it);
-                    const u32x4 sv = *(const u32x4*)(stg + sbase + ((it >> 1) * 32 + (it & 1) * 16) * L::SP);
-                    const bool live = off < OOB;                          // masked items contribute nothing to the statistics
-                    float x[8];
-                    Vec16<T>::unpack(sv, x);
-                    if constexpr (RES) {
-                        float rv[8];
-                        Vec16<T>::unpack(rr[q & 1][i], rv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = (x[e] + f2[e]) + rv[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], f1[e], f2[e]);
-                        if constexpr (MODE == 2) {
-                            if (radd) {
-                                float rv[8];
-                                Vec16<T>::unpack(rr[q & 1][i], rv);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) x[e] += rv[e];
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
-                    if (live) {                                           // exec-masked: costs scalar ops, not 8 VALU multiplies
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
-                    }
-                    asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
-                    asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (RR) { if (q + 2 < NQ) res_batch(q + 2, rr[q & 1]); }   // refill the buffer just consumed, one batch ahead
-            }
-            if (first) {
-                // publish the partial tile: every store of this wave visible at agent scope, then its flag
-                // (stores are write-through to the XCD's L2; waiting for their acknowledgement is the release -- an agent-scope
-                // release fence would write back the whole L2)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(a.kflag + (size_t)e_tile * 4 + pw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (a.part && !first) {
-#pragma unroll
-                for (int s = 16; s < 64; s <<= 1)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], s); s2[e] += __shfl_xor(s2[e], s); }
-                if (lane < 16) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { chs[(lane * 8 + e) * 2] = s1[e]; chs[(lane * 8 + e) * 2 + 1] = s2[e]; }
-                }
-                // the four waves' per-channel sums are combined into ONE slot per tile after the next workgroup barrier (combine())
-                pd_on = true; pd_b = e_b; pd_n0 = e_nt * BN;
-                pd_slot = ((e_ty * a.n_tx + e_tx) * a.npar + e_par) * a.n_nt + e_nt;
-            }
-        };
-        // After the barrier that follows an epilogue: group sums over the four producer waves' per-channel sums, one slot per
-        // (tile, group) -- a quarter of the slots a per-wave publication needs, which is what lets the consuming conv reduce
-        // them itself in one round of loads (stats() above).  Wave pw takes every fourth group of the tile's channel range;
-        // fixed summation order (lane tree), so the statistics stay run-to-run deterministic.
-        auto combine = [&]() __attribute__((always_inline)) {
-            if (!pd_on) return;
-            pd_on = false;
-            const float* const all = (const float*)(stg + L::STG_BYTES);
-            const int n0 = pd_n0;
-            if (n0 >= a.Cout) return;
-            const int nend = min(n0 + BN, a.Cout);
-            const int g1 = (nend - 1) / a.cpg;
-            for (int g = n0 / a.cpg + pw; g <= g1; g += 4) {
-                const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
-                float t1 = 0.f, t2 = 0.f;
-                const float* const wa = all + (lane >> 4) * 256;
-                for (int c = clo + (lane & 15); c < chi; c += 16) { t1 += wa[(c - n0) * 2]; t2 += wa[(c - n0) * 2 + 1]; }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) { t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
-                if (lane == 0) part_store(a.part + (size_t)(pd_b * a.G + g) * a.nslot + pd_slot, t1, t2);
-            }
-        };
-
         request_first();
         dump(0);
         request();
@@ -521,28 +548,29 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             if (k + 1 < ktotal) { prep(); dump((k + 1) & 1); }
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
-            if (epi) epi_request();
+            if (epi) epi_request(0, NQ);
             if (k + 1 < ktotal) issue();
             if (c == nck - 1) epi_setup(vb + ti * grid);           // this tile finishes in this iteration
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
-            if (epi) epilogue();
+            if (epi) epilogue(0, NQ);
             if (CCN_STAMPS_PTR(a)) t_b += __builtin_amdgcn_s_memtime() - t0;
             // last iteration (always the LAST chunk of a tile, nck >= 2, so no epilogue ran above and its registers are free):
             // fetch the last tile's bias / FiLM / first residual rows now, behind the consumers' last chunk, instead of after the
             // final barrier where nothing hides their latency.  (The second half of a split-K pair first has to see its
             // partner's flag; that wait stays behind the barrier so that it cannot hold this workgroup's consumers up.)
             const bool early = k + 1 == ktotal && !(ks == 2 && e_kh == 1);
-            if (early) epi_request();
+            if (early) epi_request(0, coop_tail ? NQ / 2 : NQ);
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
-            combine();                                             // (the sums of an epilogue that ran in this iteration)
+            combine(4);                                            // (the sums of an epilogue that ran in this iteration)
             if (++c == nck) { c = 0; ++ti; }
         }
-        if (ks == 2 && e_kh == 1) epi_request();
-        epilogue();                                                // last tile
+        if (ks == 2 && e_kh == 1) epi_request(0, NQ);
+        if (coop_tail) epilogue(0, NQ / 2); else epilogue(0, NQ);  // last tile (the consumers take the other half)
         if (pd_on) {
-            // the consumers have left (or are leaving) the kernel: a barrier now waits for the surviving waves only, i.e. the four producers
+            // all eight waves when the tail is shared; else the consumers have left (or are leaving) the kernel and the barrier
+            // waits for the surviving waves only, i.e. the four producers
             raw_barrier();
-            combine();
+            combine(coop_tail ? 8 : 4);
         }
         stamp(2); stamp_cycles();
         return;
@@ -664,6 +692,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (coop_tail) {
+            epi_setup(vb + (my_tiles - 1) * grid);
+            epi_request(NQ / 2, NQ);
+            epilogue(NQ / 2, NQ);
+            if (a.part) raw_barrier();                             // the producers combine all eight waves' sums behind it
+        }
         stamp(2); stamp_cycles();
         return;
     }
@@ -808,6 +842,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if (coop_tail) {
+        epi_setup(vb + (my_tiles - 1) * grid);
+        epi_request(NQ / 2, NQ);
+        epilogue(NQ / 2, NQ);
+        if (a.part) raw_barrier();
+    }
     stamp(2); stamp_cycles();
 }
 

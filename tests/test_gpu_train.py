@@ -459,3 +459,27 @@ def test_two_rank_bucketed_allreduce_gives_the_full_batch_gradient(tmp_path):
     g1, g2 = np.load(tmp_path / "g1.npy"), np.load(tmp_path / "g2.npy")
     assert np.abs(g1).max() > 0
     assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max(), np.abs(g1 - g2).max() / np.abs(g1).max()
+
+
+def test_c5_per_gpu_shape_bf16_vs_fp32_mode():
+    """BASELINE configs[4]'s per-GPU shape (256 px, batch 4, base 128, (1,2,2)): one loss + backward in bf16 mode against the fp32
+    parity mode of the same library (itself checked against the oracle at the sizes above) -- loss, eps and every gradient
+    tensor's direction and norm; reference loop body: train/diffusion_train.py:119-124,137."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
+    B, S = 4, 256
+    g = torch.Generator("cpu").manual_seed(55)
+    x_t = torch.randn((B, 3, S, S), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.tensor([7, 321, 654, 987]); target = torch.randn((B, 3, S, S), generator=g)
+    l32, g32, e32 = grads_via_autograd(make_net(sd, 128, (1, 2, 2)), x_t, z, t, target)
+    torch.cuda.empty_cache()
+    l16, g16, e16 = grads_via_autograd(make_net(sd, 128, (1, 2, 2), dtype="bf16"), x_t, z, t, target)
+    assert abs(float(l16) - float(l32)) < 2e-3 * float(l32), (float(l16), float(l32))
+    assert float((e16 - e32).abs().max()) < 2e-2
+    worst = ("", 1.0)
+    for k, r in g32.items():
+        a = g16[k].double().flatten(); b = r.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        if cos < worst[1]:
+            worst = (k, cos)
+        assert cos > 0.97 and 0.9 < float(a.norm() / (b.norm() + 1e-30)) < 1.1, (k, cos)
+    print(f"C5 shape 4x256x256: loss fp32 {float(l32):.5f} bf16 {float(l16):.5f}; worst gradient cosine {worst[1]:.4f} ({worst[0]})")
