@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt (experiment)
+                        if (!CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt: read once (+0.6 %)
                         else dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
                     }
                 }
