@@ -95,7 +95,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const int grid = (int)gridDim.x;
     const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int ntiles = grid_tiles;                             // virtual tiles (x2 under split-K)
-    const int my_tiles = (ntiles - vb + grid - 1) / grid;      // >= 1 (grid <= ntiles)
+    // Tile order of a workgroup: strided (vb, vb + grid, ...: at any moment the grid works on one contiguous band of tiles), or --
+    // a.blocked_per > 0, chosen by launch_conv_pr for 2-chunk layers -- blocked (vb*per, vb*per + 1, ...), which makes a
+    // workgroup's consecutive tiles NEIGHBOURS so that staged input can stay in LDS between them (a.reuse, see decode()).
+    const int per = a.blocked_per;
+    const int my_tiles = per > 0 ? min(per, ntiles - vb * per) : (ntiles - vb + grid - 1) / grid;      // >= 1 (host: grid <= ntiles, grid = ceil(ntiles / per))
+    auto vt = [&](int ti) __attribute__((always_inline)) { return per > 0 ? vb * per + ti : vb + ti * grid; };
     const int ks = a.ksplit == 2 ? 2 : 1;
     const int nck = a.nchunk / ks;                             // chunks per virtual tile
     const int ktotal = my_tiles * nck;
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int t2 = tile / a.n_nt;
         e_par = t2 % a.npar;
         const int sp = t2 / a.npar;
-        e_tx = sp % a.n_tx; e_ty = (sp / a.n_tx) % a.n_ty; e_b = sp / (a.n_tx * a.n_ty);
+        e_tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
+        e_b = sp / (a.n_tx * a.n_ty);
         const int nb = e_nt * BN + o16 * 8;
         const bool nvalid = nb < a.Cout;
         // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         u32x4 areg[AIT];
         GnCoef<T> gk;
         unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
-        bool colv = false, xv = false;           // this thread's column / extra item inside the image
+        bool colv = false, xv = false, x_vr = false;   // this thread's column / extra item inside the image; extra item reused
         int rq_ti = 0, rq_c = 0;
         // A request is split in two: prep() at the START of an iteration decodes the tile and fetches the GroupNorm
         // coefficients of the chunk into a second register set; issue() after dump() sends the 11 input loads and adopts the
@@ -421,15 +427,23 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // prep() = decode (tile / chunk of the next request) + coefficients; split so that the FIRST request of the kernel can put
         // its input loads in front of the statistics' round trip (request_first below)
         int q_cbs = 0; bool q_cv = false, q_cv_i = false;
+        bool q_skip = false, q_vr = false, d_skip = false, d_vr = false;      // wave-uniform; d_*: of the chunk whose loads are in areg
         auto decode = [&]() __attribute__((always_inline)) -> bool {
-            const int v = vb + rq_ti * grid;
+            const int v = vt(rq_ti);
             if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
-                q_tv = v < ntiles;
-                const int tile = vt_tile(q_tv ? v : vb);
+                q_tv = rq_ti < my_tiles;
+                const int tile = vt_tile(q_tv ? v : vt(0));
                 const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
-                const int tx = sp % a.n_tx, ty = (sp / a.n_tx) % a.n_ty;
+                // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
+                const int tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
                 q_b = sp / (a.n_tx * a.n_ty);
                 q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
+                // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
+                // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
+                // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
+                // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
+                q_skip = a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0;
+                q_vr = TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0;
             }
             q_c = vt_kh(v) * nck + rq_c;
             const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
@@ -470,6 +484,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int cb = cc * CKE + ck * EPC;
             const bool cv = q_tv && cb < a.Cin;
             q_cv_i = cv;
+            d_skip = q_skip; d_vr = q_vr;
+            if (d_skip) return;                                                   // the chunk is in LDS already
             // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
             // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
             // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
@@ -489,14 +505,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
 #pragma unroll
             for (int i = 0; i < HROWS; ++i) {
-                if (CCN_DBG_BIT(a, 8192)) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 2);   // nt (experiment)
-                else areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
+                if (i < 2 && d_vr) continue;                                      // rows 0, 1 come from the previous tile's rows 8, 9
+                areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
             }
             {
                 const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
                 xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
+                x_vr = d_vr && xrow < 2;                                          // (columns 32, 33 of the reused rows)
                 const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
-                areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
+                areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !x_vr) ? 0u : OOB), 0, 0);
             }
         };
         auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
@@ -513,21 +530,36 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             adopt();
         };
         auto dump = [&](int buf) __attribute__((always_inline)) {
+            if (d_skip) return;
             unsigned char* const As = smem + buf * L::A_BYTES;
             int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
             // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
             // fragment address by a constant, which lets the consumers address all three dy taps with immediate offsets
 #pragma unroll
             for (int i = 0; i < AIT; ++i) {
+                const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
+                const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
                 u32x4 v = areg[i];
+                if constexpr (TH == 8) {
+                    // vertical reuse: the finished (transformed) rows 8, 9 of the previous tile's same chunk sit in this buffer; this
+                    // thread's reads of them precede its own writes of the new rows 8, 9 below (program order, LDS in order per wave)
+                    if (i < 2 && d_vr) {
+                        *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = *(const u32x4*)(As + (px + 8 * HPITCH) * 128 + (((ck ^ sw) & 7) << 4));
+                        continue;
+                    }
+                    if (i == HROWS && d_vr) {
+                        // columns 32, 33: the copy is done by the thread that OWNS the source (halo rows 8, 9), right before it
+                        // overwrites it with the new tile's value -- a copy by the owner of rows 0, 1 would race with that write
+                        if (xthr && (pc >> 1) >= 8) *(u32x4*)(As + (px - 8 * HPITCH) * 128 + ((ck & 7) << 4)) = *(const u32x4*)(As + px * 128 + ((ck & 7) << 4));
+                        if (x_vr) continue;
+                    }
+                }
                 const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
                 if (gn) {
                     const u32x4 tr = gk.template apply<true>(v);
                     v = u32x4{0u, 0u, 0u, 0u};                                  // padding stays zero
                     if (ok) v = tr;                                             // (exec-masked move: scalar ops instead of 4 selects)
                 }
-                const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
-                const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
                 if (i < HROWS || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
                 if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
             }
@@ -550,7 +582,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
             if (epi) epi_request(0, NQ);
             if (k + 1 < ktotal) issue();
-            if (c == nck - 1) epi_setup(vb + ti * grid);           // this tile finishes in this iteration
+            if (c == nck - 1) epi_setup(vt(ti));                   // this tile finishes in this iteration
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_r += t1 - t0; t0 = t1; }
             if (epi) epilogue(0, NQ);
             if (CCN_STAMPS_PTR(a)) t_b += __builtin_amdgcn_s_memtime() - t0;
@@ -608,7 +640,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         for (int d = 0; d < 3; ++d) b16x[d] = rbase(r + d, r + d);
         u32x4 bq[DG][3];
         {
-            const unsigned wb = wbase_of(vt_tile(vb), vt_kh(vb) * nck);
+            const unsigned wb = wbase_of(vt_tile(vt(0)), vt_kh(vt(0)) * nck);
 #pragma unroll
             for (int g = 0; g < DG - 1; ++g)
 #pragma unroll
@@ -620,7 +652,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         stamp(1);
         int k = 0;
         for (int ti = 0; ti < my_tiles; ++ti) {
-            const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
+            const int v = vt(ti), v_next = ti + 1 < my_tiles ? vt(ti + 1) : v;
             const int tile = vt_tile(v), c0 = vt_kh(v) * nck;
 #pragma unroll
             for (int i = 0; i < TH; ++i)
@@ -693,7 +725,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         }
         __builtin_amdgcn_s_setprio(0);
         if (coop_tail) {
-            epi_setup(vb + (my_tiles - 1) * grid);
+            epi_setup(vt(my_tiles - 1));
             epi_request(NQ / 2, NQ);
             epilogue(NQ / 2, NQ);
             if (a.part) raw_barrier();                             // the producers combine all eight waves' sums behind it
@@ -726,7 +758,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
     u32x4 bq[D][NF];
     {
-        const unsigned wb = wbase_of(vt_tile(vb), vt_kh(vb) * nck);
+        const unsigned wb = wbase_of(vt_tile(vt(0)), vt_kh(vt(0)) * nck);
 #pragma unroll
         for (int s = 0; s < D - 1; ++s)
 #pragma unroll
@@ -739,7 +771,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     stamp(1);
     int k = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        const int v = vb + ti * grid, v_next = v + grid < ntiles ? v + grid : v;
+        const int v = vt(ti), v_next = ti + 1 < my_tiles ? vt(ti + 1) : v;
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
         int toffs[NTAPS == 9 ? 1 : NTAPS], tdxs[NTAPS == 9 ? 1 : NTAPS];   // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
@@ -843,7 +875,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     }
     __builtin_amdgcn_s_setprio(0);
     if (coop_tail) {
-        epi_setup(vb + (my_tiles - 1) * grid);
+        epi_setup(vt(my_tiles - 1));
         epi_request(NQ / 2, NQ);
         epilogue(NQ / 2, NQ);
         if (a.part) raw_barrier();
@@ -924,6 +956,22 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // every round of the persistent loop.  Fewer than 16 virtual tiles: the layer is too small for this kernel anyway.
     if (ks == 2) { grid &= ~15; if (grid < 16) return hipErrorInvalidValue; }
     ConvArgs d = a;
+    // 2-chunk layers with one N tile (the 128-channel levels of C2): blocked tile order + input kept in LDS between neighbouring
+    // tiles.  ConvTranspose: the four parities of a spatial tile (consecutive tile ids) share their staged input; 3x3 s1: a tile
+    // reuses the two bottom halo rows of the tile above it.
+    d.blocked_per = 0; d.reuse = 0;
+#ifdef CCN_NO_REUSE
+    static const bool no_reuse = true;                                        // A/B build (make ab EXTRA=-DCCN_NO_REUSE)
+#else
+    static const bool no_reuse = diag_env("CCN_NO_REUSE") != nullptr;
+#endif
+    if (!no_reuse && ks == 1 && a.n_nt == 1 && a.nchunk == 2 && ntiles > grid && (ct || (c3 && a.th == 8 && a.n_ty > 1))) {
+        const int per = (ntiles + grid - 1) / grid;
+        if (!ct || (per & 3) == 0) {
+            d.blocked_per = per; d.reuse = ct ? 1 : 2;
+            grid = (ntiles + per - 1) / per;
+        }
+    }
     static const char* env = diag_env("CCN_STAMPS");
     if (env && (unsigned)atoi(env) == (unsigned)ntiles && (!strchr(env, ':') || atoi(strchr(env, ':') + 1) == a.ntaps)) {   // CCN_STAMPS=<tiles>[:<ntaps>]
         if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }
