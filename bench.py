@@ -33,7 +33,7 @@ import torch
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
 
 
 def main() -> None:
