@@ -38,6 +38,7 @@ SIGNATURES = {
     "ccn_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
     "ccn_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_sample": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp, c_i32]),
+    "ccn_sample_eta": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_i32]),
     "ccn_ddim_step": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp]),
     "ccn_q_sample": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp]),
     "ccn_predict_x0": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp]),
@@ -224,7 +225,9 @@ class NativeUNet:
                                        ws.ptr, ws.nbytes, current_stream(x.device)))
         return out
 
-    def sample(self, z: torch.Tensor, x_T: torch.Tensor, ts, coef, use_graph: bool = True, slot: int = 0) -> torch.Tensor:
+    def sample(self, z: torch.Tensor, x_T: torch.Tensor, ts, coef, use_graph: bool = True, slot: int = 0,
+               sigma=None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``sigma`` (steps,) + ``noise`` (steps, B, C, H, W) fp32 on the device: the eta > 0 loop (ccn_sample_eta)."""
         import numpy as np
         z = require_dev(z, "z_clip"); x_T = require_dev(x_T, "x_T")
         B, C, H, W = x_T.shape
@@ -238,9 +241,18 @@ class NativeUNet:
         ws = self.workspace(B, H, W, steps, slot)
         out = torch.empty_like(x_T)
         with torch.cuda.device(x_T.device):
-            check(self.lib.ccn_sample(self.h, z.data_ptr(), x_T.data_ptr(), out.data_ptr(), B, H, W, steps,
-                                      ts.ctypes.data, coef.ctypes.data, ws.ptr, ws.nbytes,
-                                      current_stream(x_T.device), 1 if use_graph else 0))
+            if sigma is not None:
+                sigma = np.ascontiguousarray(sigma, dtype=np.float32)
+                noise = require_dev(noise, "noise")
+                if sigma.shape != (steps,) or tuple(noise.shape) != (steps, B, C, H, W):
+                    raise ValueError(f"sigma must be ({steps},) and noise ({steps}, {B}, {C}, {H}, {W})")
+                check(self.lib.ccn_sample_eta(self.h, z.data_ptr(), x_T.data_ptr(), out.data_ptr(), B, H, W, steps,
+                                              ts.ctypes.data, coef.ctypes.data, sigma.ctypes.data, noise.data_ptr(), ws.ptr, ws.nbytes,
+                                              current_stream(x_T.device), 1 if use_graph else 0))
+            else:
+                check(self.lib.ccn_sample(self.h, z.data_ptr(), x_T.data_ptr(), out.data_ptr(), B, H, W, steps,
+                                          ts.ctypes.data, coef.ctypes.data, ws.ptr, ws.nbytes,
+                                          current_stream(x_T.device), 1 if use_graph else 0))
         return out
 
     def resblock(self, prefix: str, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:

@@ -2,12 +2,13 @@
 
 Interface of ``diffusion/ddim.py:14-45`` of the reference.  Two execution routes, same numbers:
 
-* fused  -- ``model`` is this package's ``CLIPCondUNet`` and ``eta == 0``: the timestep table and the
+* fused  -- ``model`` is this package's ``CLIPCondUNet``: the timestep table and the
   per-step coefficients are computed on the host (no ``.item()`` syncs inside the loop), conditioning
   for all steps is hoisted in front of the loop, and the ``steps`` UNet evaluations + DDIM updates
-  replay as ONE captured hipGraph (``ccn_sample``).
-* stepwise -- any other callable ``model(x, z, t)`` or ``eta > 0``: one ``model`` call and one
-  ``ccn_ddim_step`` kernel per step; the ``eta > 0`` noise comes from ``torch.randn_like`` on the device.
+  replay as ONE captured hipGraph (``ccn_sample``; ``eta > 0``: ``ccn_sample_eta``, the N(0,1) draws of all steps made up
+  front, one ``normal_()`` per noisy step in loop order, so the torch generator is consumed exactly as by the stepwise loop).
+* stepwise -- any other callable ``model(x, z, t)``: one ``model`` call and one ``ccn_ddim_step`` kernel per step; the
+  ``eta > 0`` noise comes from ``torch.randn_like`` on the device.
 
 Reference behaviours kept on purpose: ``ts = linspace(T-1, 0, steps).long()``; ``alpha_bar_prev`` is
 ``alphas_cumprod_prev[t]`` (not the next sampled step) and 1.0 on the last step; the direction term is
@@ -30,6 +31,7 @@ class DDIMSampler:
         self.sch = scheduler
         self.eta = eta
         self.use_graph = True
+        self._noise: dict = {}
 
     @torch.no_grad()
     def sample(self, model, z_clip: torch.Tensor, shape: tuple, steps: int = 50, cfg_scale: float = 1.0,
@@ -40,8 +42,19 @@ class DDIMSampler:
         ts = self.sch.ddim_timesteps(steps)
         coef = self.sch.ddim_coefficients(steps, self.eta)
         x = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
-        if self.eta == 0 and hasattr(model, "sample_ddim"):
-            return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph, slot=slot)
+        if hasattr(model, "sample_ddim"):
+            if self.eta == 0:
+                return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph, slot=slot)
+            # eta > 0: every noisy step's draw up front, into a buffer kept per (shape, steps, slot) so that the captured graph
+            # (keyed by the buffer's address) is replayed by later calls
+            key = (tuple(shape), steps, slot, str(device))
+            buf = self._noise.get(key)
+            if buf is None:
+                buf = self._noise[key] = torch.empty((steps,) + tuple(shape), dtype=torch.float32, device=device)
+            for i in range(steps):
+                if float(coef[i, 4]) > 0:
+                    buf[i].normal_()                                  # == torch.randn_like(x): same generator, same order
+            return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph, slot=slot, sigma=coef[:, 4], noise=buf)
         x = _native.require_dev(x, "x_T").clone()
         for i in range(steps):
             t_b = torch.full((shape[0],), int(ts[i]), device=device, dtype=torch.long)

@@ -158,10 +158,10 @@ class CLIPCondUNet(nn.Module):
     # ------------------------------------------------------------------ fused sampling
     @torch.no_grad()
     def sample_ddim(self, z_clip: torch.Tensor, x_T: torch.Tensor, ts: Sequence[int], coef: np.ndarray,
-                    use_graph: bool = True, slot: int = 0) -> torch.Tensor:
+                    use_graph: bool = True, slot: int = 0, sigma=None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """All DDIM steps (eta = 0) inside the library; see ``ccn_sample`` in include/ccn_hip.h.  ``slot`` selects an independent
         workspace / captured graph, so that consecutive batches can be in flight on different streams."""
-        return self.native(x_T.device).sample(z_clip, x_T, ts, coef, use_graph=use_graph, slot=slot)
+        return self.native(x_T.device).sample(z_clip, x_T, ts, coef, use_graph=use_graph, slot=slot, sigma=sigma, noise=noise)
 
     def read_activation(self, name: str, shape) -> torch.Tensor:
         return self.native().read_activation(name, tuple(shape))

@@ -89,6 +89,8 @@ struct StepCtx {
     float* eps_out = nullptr;
     int do_ddim = 0;
     float c[4] = {0, 0, 0, 0};
+    const float* noise = nullptr;  // eta > 0: this step's noise tensor (sigma > 0), else null
+    float sigma = 0.f;
 };
 
 struct Launch {
@@ -113,6 +115,8 @@ struct GraphEntry {
     int steps = 0;
     std::vector<int32_t> ts;
     std::vector<float> coef;
+    std::vector<float> sigma;            // eta > 0 (empty: eta = 0)
+    const float* noise = nullptr;        // ... and the address of the caller's noise tensor the graph was captured with
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 };
@@ -542,6 +546,7 @@ struct PlanBuilder {
             if (is_head) {
                 k.x_state = c.x_state; k.eps_out = c.eps_out; k.do_ddim = c.do_ddim;
                 k.c0 = c.c[0]; k.c1 = c.c[1]; k.c2 = c.c[2]; k.c3 = c.c[3];
+                k.noise = c.noise; k.sigma = c.sigma;
             }
             return launch_conv(dtype, kind, bn, k, s);
         };
@@ -732,6 +737,7 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
                         ConvArgs k = *ap;
                         k.x_state = sc.x_state; k.eps_out = sc.eps_out; k.do_ddim = sc.do_ddim;
                         k.c0 = sc.c[0]; k.c1 = sc.c[1]; k.c2 = sc.c[2]; k.c3 = sc.c[3];
+                        k.noise = sc.noise; k.sigma = sc.sigma;
                         return launch_head2(k, ab, wf, scratch, s);
                     };
                     plan->ops.push_back(std::move(Lh));
@@ -833,12 +839,14 @@ int run_conditioning(ccn_handle_s* h, Plan* p, hipStream_t s, const int64_t* t_i
     return CCN_OK;
 }
 
-int run_steps(ccn_handle_s* h, Plan* p, hipStream_t s, int steps, const float* coef)
+int run_steps(ccn_handle_s* h, Plan* p, hipStream_t s, int steps, const float* coef, const float* sigma = nullptr, const float* noise = nullptr)
 {
+    const size_t img = (size_t)p->B * h->cfg.img_ch * p->H * p->W;
     for (int i = 0; i < steps; ++i) {
         StepCtx c;
         c.step = i; c.x_in = p->xstate; c.x_state = p->xstate; c.eps_out = nullptr; c.do_ddim = 1;
         for (int k = 0; k < 4; ++k) c.c[k] = coef[i * 4 + k];
+        if (sigma && noise && sigma[i] > 0.f) { c.noise = noise + (size_t)i * img; c.sigma = sigma[i]; }
         for (auto& L : p->ops) { int rc = run_launch(h, L, s, c); if (rc) return rc; }
     }
     return CCN_OK;
@@ -1054,9 +1062,9 @@ int ccn_forward(ccn_handle_t h, const float* x_dev, const float* z_dev, const in
     return CCN_OK;
 }
 
-int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev, int32_t B, int32_t H, int32_t W,
-               int32_t steps, const int32_t* ts_host, const float* coef_host, void* workspace_dev, size_t workspace_bytes,
-               void* stream, int32_t use_graph)
+static int sample_impl(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev, int32_t B, int32_t H, int32_t W,
+                       int32_t steps, const int32_t* ts_host, const float* coef_host, const float* sigma_host, const float* noise_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream, int32_t use_graph)
 {
     int rc = check_ready(h);
     if (rc) return rc;
@@ -1079,13 +1087,17 @@ int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* 
         GraphEntry* ge = nullptr;
         for (auto& g : p->graphs)
             if (g.steps == steps && !std::memcmp(g.ts.data(), ts_host, (size_t)steps * 4) &&
-                !std::memcmp(g.coef.data(), coef_host, (size_t)steps * 16)) { ge = &g; break; }
+                !std::memcmp(g.coef.data(), coef_host, (size_t)steps * 16) && g.noise == noise_dev &&
+                g.sigma.size() == (sigma_host ? (size_t)steps : 0) &&
+                (!sigma_host || !std::memcmp(g.sigma.data(), sigma_host, (size_t)steps * 4))) { ge = &g; break; }
         if (!ge) {
             GraphEntry g;
             g.steps = steps; g.ts.assign(ts_host, ts_host + steps); g.coef.assign(coef_host, coef_host + steps * 4);
+            if (sigma_host) g.sigma.assign(sigma_host, sigma_host + steps);
+            g.noise = noise_dev;
             HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
             rc = run_conditioning(h, p, h->cap_stream, nullptr, steps, steps * B, B);
-            if (!rc) rc = run_steps(h, p, h->cap_stream, steps, coef_host);
+            if (!rc) rc = run_steps(h, p, h->cap_stream, steps, coef_host, sigma_host, noise_dev);
             hipGraph_t graph = nullptr;
             const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1098,10 +1110,25 @@ int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* 
         HIPCHK(hipGraphLaunch(ge->exec, s));
     } else {
         if ((rc = run_conditioning(h, p, s, nullptr, steps, steps * B, B))) return rc;
-        if ((rc = run_steps(h, p, s, steps, coef_host))) return rc;
+        if ((rc = run_steps(h, p, s, steps, coef_host, sigma_host, noise_dev))) return rc;
     }
     if (x_out_dev != p->xstate) HIPCHK(hipMemcpyAsync(x_out_dev, p->xstate, img_bytes, hipMemcpyDeviceToDevice, s));
     return CCN_OK;
+}
+
+int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev, int32_t B, int32_t H, int32_t W,
+               int32_t steps, const int32_t* ts_host, const float* coef_host, void* workspace_dev, size_t workspace_bytes,
+               void* stream, int32_t use_graph)
+{
+    return sample_impl(h, z_dev, x_T_dev, x_out_dev, B, H, W, steps, ts_host, coef_host, nullptr, nullptr, workspace_dev, workspace_bytes, stream, use_graph);
+}
+
+int ccn_sample_eta(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev, int32_t B, int32_t H, int32_t W,
+                   int32_t steps, const int32_t* ts_host, const float* coef_host, const float* sigma_host, const float* noise_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream, int32_t use_graph)
+{
+    if (!sigma_host || !noise_dev) return fail(CCN_EINVAL, "null sigma / noise");
+    return sample_impl(h, z_dev, x_T_dev, x_out_dev, B, H, W, steps, ts_host, coef_host, sigma_host, noise_dev, workspace_dev, workspace_bytes, stream, use_graph);
 }
 
 int ccn_ddim_step(float* x_dev, const float* eps_dev, const float* noise_dev, float c0, float c1, float c2, float c3,

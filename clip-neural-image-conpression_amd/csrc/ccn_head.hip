@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsig
             const float xs = a.x_state[idx];
             float x0v = __fdiv_rn(__fsub_rn(xs, __fmul_rn(a.c0, e)), a.c1);
             x0v = fminf(fmaxf(x0v, -1.0f), 1.0f);
-            a.x_state[idx] = __fadd_rn(__fmul_rn(a.c2, x0v), __fmul_rn(a.c3, e));
+            float xn = __fadd_rn(__fmul_rn(a.c2, x0v), __fmul_rn(a.c3, e));
+            if (a.noise) xn = __fadd_rn(xn, __fmul_rn(a.sigma, a.noise[idx]));      // eta > 0 (diffusion/ddim.py:44-45)
+            a.x_state[idx] = xn;
         }
     }
 }

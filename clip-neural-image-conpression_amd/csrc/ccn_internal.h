@@ -60,6 +60,8 @@ struct ConvArgs {
     float* x_state;         // head: DDIM state, NCHW fp32, updated in place when do_ddim
     float* eps_out;         // head: eps NCHW fp32, or null
     float c0, c1, c2, c3;   // head: DDIM coefficients
+    const float* noise;     // head: eta > 0 -- this step's N(0,1) tensor, NCHW fp32 like x_state (added as sigma * noise), or null
+    float sigma;
     int do_ddim;
     int film_bstride;
     int B, Hin, Win, Cin, Cin_pad, Hout, Wout, Cout, Cout_pad;

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                         const float x = a.x_state[idx];
                         float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(a.c0, e)), a.c1);
                         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-                        a.x_state[idx] = __fadd_rn(__fmul_rn(a.c2, x0), __fmul_rn(a.c3, e));
+                        float xn = __fadd_rn(__fmul_rn(a.c2, x0), __fmul_rn(a.c3, e));
+                        if (a.noise) xn = __fadd_rn(xn, __fmul_rn(a.sigma, a.noise[idx]));      // eta > 0 (diffusion/ddim.py:44-45)
+                        a.x_state[idx] = xn;
                     }
                 }
             }

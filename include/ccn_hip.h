@@ -98,6 +98,16 @@ int ccn_sample(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* 
                const int32_t* ts_host, const float* coef_host,
                void* workspace_dev, size_t workspace_bytes, void* stream, int32_t use_graph);
 
+/* The same loop for eta > 0 (diffusion/ddim.py:41-45): sigma_host[steps] fp32 per-step sigma (0 on steps without noise, e.g. the
+ * last one), coef_host as above with c3 = sqrt(ab_s - sigma^2); noise_dev (steps,B,img_ch,H,W) fp32 holds the N(0,1) draws of every
+ * step, made by the caller (the reference draws torch.randn_like per step: a torch caller fills slice i with its i-th draw so that
+ * the fused loop consumes the generator exactly like the step-by-step loop); the update adds sigma*noise, rounded like the torch ops.
+ * The captured graph is cached per (table, sigma, noise address). */
+int ccn_sample_eta(ccn_handle_t h, const float* z_dev, const float* x_T_dev, float* x_out_dev,
+                   int32_t B, int32_t H, int32_t W, int32_t steps,
+                   const int32_t* ts_host, const float* coef_host, const float* sigma_host, const float* noise_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream, int32_t use_graph);
+
 /* One DDIM update outside the fused loop (eta > 0, or a caller-driven loop; diffusion/ddim.py:34-45):
  * x = c2*clamp((x - c0*eps)/c1) + c3*eps [+ sigma*noise]; noise_dev may be NULL. In place on x_dev. */
 int ccn_ddim_step(float* x_dev, const float* eps_dev, const float* noise_dev,

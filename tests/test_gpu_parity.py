@@ -192,10 +192,36 @@ def test_batch_rows_are_independent(synth, tiny_net):
         assert torch.equal(one[0], full[i]), i
 
 
-def test_eta_positive_runs_stepwise(tiny_net, synth):
-    z = to_dev(synth.synth_z(1)); xT = to_dev(synth.start_noise([0], 32))
-    x = DDIMSampler(NoiseScheduler(1000, "linear", DEV), eta=0.3).sample(tiny_net, z, (1, 3, 32, 32), steps=5, x_T=xT)
-    assert x.shape == (1, 3, 32, 32)
+def test_eta_positive_fused_graph_matches_oracle_and_stepwise(tiny_net, tiny_sd, synth):
+    """eta > 0 (diffusion/ddim.py:41-45) through the fused graph (ccn_sample_eta): the per-step N(0,1) draws are made up front, one
+    ``normal_()`` per noisy step in loop order.  (a) Against the CPU oracle fed the SAME draws: the C1 gate of the eta = 0 path;
+    (b) against the step-by-step route (generic callable + ccn_ddim_step, ``torch.randn_like`` per step) after re-seeding the device
+    generator: equal to the 1e-5 of the two conditioning paths, which shows the generator is consumed identically; (c) the second
+    call replays the captured graph (same noise buffer address) and, re-seeded, reproduces the first bit for bit."""
+    # (the reference's direction term sqrt(ab_s - sigma^2) with ab_s = alphas_cumprod_prev[t] goes NaN at the noisy end of the
+    # schedule unless eta^2 beta_t < ab_s: linear schedule, eta = 0.03 keeps every step real)
+    B, S, T, eta = 2, 32, 6, 0.03
+    z = to_dev(synth.synth_z(B)); xT = to_dev(synth.start_noise(range(B), S))
+    sch = NoiseScheduler(1000, "linear", DEV)
+    assert np.isfinite(sch.ddim_coefficients(T, eta)).all()
+    assert (sch.ddim_coefficients(T, eta)[:-1, 4] > 0).all() and sch.ddim_coefficients(T, eta)[-1, 4] == 0    # last step: no noise
+    sampler = DDIMSampler(sch, eta=eta)
+    torch.manual_seed(1234)
+    a = sampler.sample(tiny_net, z, (B, 3, S, S), steps=T, x_T=xT)
+    draws = next(iter(sampler._noise.values())).cpu().clone()               # what the fused loop consumed
+    it = iter(range(T))
+    ref = ref_diffusion.ddim_sample(ref_unet.make_model(ref_unet.as_torch_sd(tiny_sd)), z.cpu(), xT.cpu(), steps=T, schedule="linear", eta=eta,
+                                    noise_fn=lambda x: draws[next(it)])
+    assert maxerr(a, ref) < TOL_E2E_FP32, maxerr(a, ref)
+    torch.manual_seed(1234)
+    b = sampler.sample(lambda x, zz, t: tiny_net(x, zz, t), z, (B, 3, S, S), steps=T, x_T=xT)      # stepwise route
+    assert maxerr(a, b) < 1e-5, maxerr(a, b)
+    torch.manual_seed(1234)
+    c = sampler.sample(tiny_net, z, (B, 3, S, S), steps=T, x_T=xT)
+    assert torch.equal(a, c)
+    torch.manual_seed(99)
+    d = sampler.sample(tiny_net, z, (B, 3, S, S), steps=T, x_T=xT)
+    assert maxerr(a, d) > 1e-3                                              # other draws, other sample
 
 
 def test_error_paths(tiny_net):
