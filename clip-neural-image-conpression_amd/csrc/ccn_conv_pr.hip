@@ -15,9 +15,19 @@
 //     tile in LDS (32 ds_write_b64 per wave; the MFMA operands are swapped so a lane holds 4 consecutive channels of
 //     one pixel) and go straight on to the next tile.  The PRODUCER waves -- idle most of a chunk -- finish the
 //     previous tile during the next tile's first chunk: staging -> bias / FiLM / residual (rows prefetched into their
-//     registers one chunk earlier) -> 16-byte NHWC stores, and the next GroupNorm's partial sums (one slot per
-//     producer wave).
-// Tile: 8 rows x 32 pixels x 128 output channels, 4 consumer waves (2x2, 4x2 fragments of 32x32) + 4 producer waves.
+//     registers one chunk earlier) -> 16-byte write-through NHWC stores, and the next GroupNorm's partial sums (the four
+//     producer waves' per-channel sums are combined in LDS after the next barrier: ONE slot per tile).
+// Round 2 (what the stamps of a one-tile-per-CU launch showed: 5 us until the first chunk is visible, 4 us of tail, and a
+// 5 us finalize launch + kernel boundary in front of every conv):
+//   * the input GroupNorm's finalize is done here: every producer wave reduces the producer kernel's partial sums of the
+//     sample it is about to stage (<= 64 slots per group, one round of loads issued next to the first input loads);
+//   * the LAST tile's epilogue is split between the two roles (the consumers have nothing left to overlap it with) and its
+//     bias / FiLM / residual operands are fetched before the final barrier of the chunk loop;
+//   * TH = 4: the same kernel on 4-row tiles for layers with fewer than #CUs 8-row tiles;
+//   * blocked tile order for 2-chunk layers, where chunk c of every tile lives in LDS buffer c: the four ConvTranspose
+//     parities of a spatial tile stage their input once, a 3x3 tile copies its two top halo rows from the tile above it.
+// Tile: TH (8 or 4) rows x 32 pixels x 128 output channels, 4 consumer waves (3x3: all rows x 32 channels each; other tap sets:
+// 2x2 waves of 4x2 fragments of 32x32) + 4 producer waves.
 // Rounding: the conv accumulator is rounded to bf16 once before the affine/residual and the sum once more on store
 // (the other kernels round once); both are within the bf16 mode's error budget (tests/test_gpu_parity.py bounds).
 #include "ccn_device.h"
