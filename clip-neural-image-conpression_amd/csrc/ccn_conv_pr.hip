@@ -371,212 +371,224 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // (its hand-off flags are per producer wave).
     const bool coop_tail = ks == 1 && !CCN_DBG_BIT(a, 1024);
 
+    // ---- input staging machinery (role-neutral like the epilogue's: the producers run it for every chunk; the consumers,
+    // idle until the first chunk is in LDS, stage the lower half of the halo rows of that first chunk themselves)
+    const int ptid = tid & 255;
+    const int ck = ptid & 7, pcol = ptid >> 3;                // 16-byte channel slice, halo column 0..31
+    // the two halo columns 32, 33 (HROWS rows x 8 slices = 160 units at 8 rows) go to threads 0..HROWS*16-1 as one more item
+    const int xrow = pcol >> 1, xcol = 32 + (pcol & 1);
+    const bool xthr = ptid < HROWS * 16;
+    constexpr int AIT = HROWS + 1;
+    u32x4 areg[AIT];
+    GnCoef<T> gk;
+    unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
+    bool colv = false, xv = false, x_vr = false;   // this thread's column / extra item inside the image; extra item reused
+    int rq_ti = 0, rq_c = 0;
+    // A request is split in two: prep() at the START of an iteration decodes the tile and fetches the GroupNorm
+    // coefficients of the chunk into a second register set; issue() after dump() sends the 11 input loads and adopts the
+    // coefficients.  (Fetched inside issue(), the coefficient loads made the wave wait a full L2 latency right there.)
+    GnCoef<T> gkn;
+    int q_b = 0, q_iy0 = 0, q_ix0 = 0, q_c = 0;
+    bool q_tv = false;
+    // in-kernel finalize (gstat): every producer wave reduces the partial sums of the sample it is about to stage by itself
+    // (no cross-wave step): lane l sums slots (l & 7), (l & 7) + 8, ... of group l >> 3 -- 8 groups x 8 lanes -- in fp64 and
+    // three xor-shuffles leave (mean, 1/sqrt(var + eps)) of group l >> 3 in every lane; a thread's 8 channels lie in one
+    // group (cpg % 8 == 0, checked on the host) whose statistics it fetches with a lane permute; gamma / beta of those
+    // channels are loaded raw in prep() and folded into (scale, shift) in issue(), one dump later, so nothing waits for them.
+    float st_mean = 0.f, st_rstd = 1.f, qn_mean = 0.f, qn_rstd = 1.f;
+    int st_b = -1;
+    f32x4 qn_g[2], qn_bt[2];
+    float2 sv[8];                            // one round of partial-sum loads (stats_issue -> stats_reduce)
+    auto stats_issue = [&](int b) __attribute__((always_inline)) {
+        const int g = lane >> 3, sub = lane & 7;
+        const int cpg = a.gs_cpg, pbn = a.gs_bn, pnt = a.gs_nnt;
+        const int jlo = (g * cpg) / pbn, jhi = ((g + 1) * cpg - 1) / pbn, nj = jhi - jlo + 1;
+        const int ne = a.gs_nsp * nj;                                  // <= 64 (host: in_kernel_stats)
+        const float2* const base = a.gs_part + (size_t)(b * 8 + g) * ((size_t)a.gs_nsp * pnt);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = sub + 8 * u;
+            sv[u] = make_float2(0.f, 0.f);
+            if (e < ne) {
+                int sp = e, j = jlo;
+                if (nj != 1) { sp = e / nj; j = jlo + (e - sp * nj); }
+                sv[u] = base[(size_t)sp * pnt + j];
+            }
+        }
+    };
+    auto stats_reduce = [&]() __attribute__((always_inline)) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)sv[u].x; s2 += (double)sv[u].y; }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        const double mean = s1 * a.gs_inv_count;
+        double var = s2 * a.gs_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st_mean = (float)mean;
+        st_rstd = __builtin_amdgcn_rsqf((float)(var + 1e-5));
+    };
+    // prep() = decode (tile / chunk of the next request) + coefficients; split so that the FIRST request of the kernel can put
+    // its input loads in front of the statistics' round trip (request_first below)
+    int q_cbs = 0; bool q_cv = false, q_cv_i = false;
+    bool q_skip = false, q_vr = false, d_skip = false, d_vr = false;      // wave-uniform; d_*: of the chunk whose loads are in areg
+    auto decode = [&]() __attribute__((always_inline)) -> bool {
+        const int v = vt(rq_ti);
+        if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
+            q_tv = rq_ti < my_tiles;
+            const int tile = vt_tile(q_tv ? v : vt(0));
+            const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+            // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
+            const int tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
+            q_b = sp / (a.n_tx * a.n_ty);
+            q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
+            // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
+            // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
+            // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
+            // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
+            q_skip = a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0;
+            q_vr = TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0;
+        }
+        q_c = vt_kh(v) * nck + rq_c;
+        const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
+        q_cv = q_tv && cb < a.Cin;
+        q_cbs = q_cv ? cb : 0;
+        const bool fresh = gstat && rq_c == 0 && q_tv && q_b != st_b;  // wave-uniform: statistics of another sample needed
+        if (++rq_c == nck) { rq_c = 0; ++rq_ti; }
+        return fresh;
+    };
+    auto coef_loads = [&]() __attribute__((always_inline)) {
+        if (gstat) {
+            qn_g[0] = *(const f32x4*)(a.gs_gamma + q_cbs); qn_g[1] = *(const f32x4*)(a.gs_gamma + q_cbs + 4);
+            qn_bt[0] = *(const f32x4*)(a.gs_beta + q_cbs); qn_bt[1] = *(const f32x4*)(a.gs_beta + q_cbs + 4);
+        } else gkn.load(a.gn_ab + (size_t)q_b * a.Cin + q_cbs, gn && q_cv);
+    };
+    auto coef_sel = [&]() __attribute__((always_inline)) {
+        if (gstat) {
+            const int src = (q_cbs / a.gs_cpg) * 8;                    // a lane that holds the statistics of the channels' group
+            qn_mean = __shfl(st_mean, src); qn_rstd = __shfl(st_rstd, src);
+        }
+    };
+    auto prep = [&]() __attribute__((always_inline)) {
+        const bool fresh = decode();
+        coef_loads();
+        if (fresh) { stats_issue(q_b); stats_reduce(); st_b = q_b; }
+        coef_sel();
+    };
+    auto adopt = [&]() __attribute__((always_inline)) {
+        if (gstat) gk.from_raw(qn_g, qn_bt, qn_mean, qn_rstd, gn && q_cv_i);
+        else gk = gkn;
+    };
+    // rows [r0, r1) of the halo tile (+ the columns-32/33 item when with_x); call sites pass constants
+    auto issue_loads = [&](int r0 = 0, int r1 = TH + 2, bool with_x = true) __attribute__((always_inline)) {
+        // (readfirstlane: these are wave-uniform by construction; saying so keeps the descriptor in SGPRs)
+        const int b = __builtin_amdgcn_readfirstlane(q_b), iy0 = __builtin_amdgcn_readfirstlane(q_iy0), ix0 = __builtin_amdgcn_readfirstlane(q_ix0);
+        const int cc = __builtin_amdgcn_readfirstlane(S2 ? q_c / 5 : q_c);     // channel chunk
+        const int pass = S2 ? q_c - cc * 5 : 0;
+        const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
+        const int cb = cc * CKE + ck * EPC;
+        const bool cv = q_tv && cb < a.Cin;
+        q_cv_i = cv;
+        d_skip = q_skip; d_vr = q_vr;
+        if (d_skip) return;                                                   // the chunk is in LDS already
+        // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
+        // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
+        // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
+        // per-row compare; only the column validity (and the channel tail) is per lane, ORed in as an out-of-range constant.
+        const unsigned img_bytes = (unsigned)(a.Hin * a.Win * a.Cin) * (unsigned)sizeof(T);
+        const unsigned coff = (unsigned)(((q_tv && cc * CKE < a.Cin) ? cc : 0) * CKE) * (unsigned)sizeof(T);
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + (size_t)b * img_bytes + coff), 0, img_bytes - coff, 0x00020000);
+        const int rs = IS * a.Win * a.Cin * (int)sizeof(T);                   // row stride of the staged plane in bytes
+        const int ixr = IS * (ix0 + pcol) + px;                               // input column of this thread's halo column
+        colv = cv && ixr >= 0 && ixr < a.Win;
+        const unsigned cmask = colv ? 0u : OOB;
+        const int base = ((IS * iy0 + py) * a.Win + ixr) * a.Cin * (int)sizeof(T) + ck * 16;
+        // halo rows inside the image: [r_lo, r_hi) (wave-uniform), as a bit mask for the padding-stays-zero select in dump()
+        const int first = IS * iy0 + py;                                      // input row of halo row 0
+        const int r_lo = first < 0 ? (-first + IS - 1) / IS : 0;
+        int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > HROWS ? HROWS : (r_hi < 0 ? 0 : r_hi);
+        rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
+#pragma unroll
+        for (int i = 0; i < HROWS; ++i) {
+            if (i < r0 || i >= r1) continue;
+            if (i < 2 && d_vr) continue;                                      // rows 0, 1 come from the previous tile's rows 8, 9
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
+        }
+        {
+            const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
+            xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
+            x_vr = d_vr && xrow < 2;                                          // (columns 32, 33 of the reused rows)
+            const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
+            if (with_x) areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !x_vr) ? 0u : OOB), 0, 0);
+        }
+    };
+    auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
+    auto request = [&]() __attribute__((always_inline)) { prep(); issue(); };
+    // the kernel's first request: input loads go out BEFORE the wave waits for the partial sums (one memory round trip for
+    // everything the first dump needs instead of two)
+    auto request_first = [&](int r0, int r1, bool with_x) __attribute__((always_inline)) {
+        const bool fresh = decode();
+        if (fresh) stats_issue(q_b);
+        coef_loads();
+        issue_loads(r0, r1, with_x);
+        if (fresh) { stats_reduce(); st_b = q_b; }
+        coef_sel();
+        adopt();
+    };
+    auto dump = [&](int buf, int r0 = 0, int r1 = TH + 2, bool with_x = true) __attribute__((always_inline)) {
+        if (d_skip) return;
+        unsigned char* const As = smem + buf * L::A_BYTES;
+        int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
+        // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
+        // fragment address by a constant, which lets the consumers address all three dy taps with immediate offsets
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            if (i < HROWS ? (i < r0 || i >= r1) : !with_x) continue;
+            const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
+            const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
+            u32x4 v = areg[i];
+            if constexpr (TH == 8) {
+                // vertical reuse: the finished (transformed) rows 8, 9 of the previous tile's same chunk sit in this buffer; this
+                // thread's reads of them precede its own writes of the new rows 8, 9 below (program order, LDS in order per wave)
+                if (i < 2 && d_vr) {
+                    *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = *(const u32x4*)(As + (px + 8 * HPITCH) * 128 + (((ck ^ sw) & 7) << 4));
+                    continue;
+                }
+                if (i == HROWS && d_vr) {
+                    // columns 32, 33: the copy is done by the thread that OWNS the source (halo rows 8, 9), right before it
+                    // overwrites it with the new tile's value -- a copy by the owner of rows 0, 1 would race with that write
+                    if (xthr && (pc >> 1) >= 8) *(u32x4*)(As + (px - 8 * HPITCH) * 128 + ((ck & 7) << 4)) = *(const u32x4*)(As + px * 128 + ((ck & 7) << 4));
+                    if (x_vr) continue;
+                }
+            }
+            const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
+            if (gn) {
+                const u32x4 tr = gk.template apply<true>(v);
+                v = u32x4{0u, 0u, 0u, 0u};                                  // padding stays zero
+                if (ok) v = tr;                                             // (exec-masked move: scalar ops instead of 4 selects)
+            }
+            if (i < HROWS || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
+        }
+    };
+
+    // first chunk of the launch: halo rows [0, HSPLIT) + the extra columns by the producers, [HSPLIT, HROWS) by the consumers
+#ifdef CCN_NO_COOP_HEAD
+    constexpr int HSPLIT = HROWS;                                  // A/B build: producers stage all of it
+#else
+    constexpr int HSPLIT = HROWS / 2;
+#endif
+
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers (4 waves): input chunks + tile epilogues
         // The VALU is the scarce resource here (GroupNorm + SiLU costs ~45 VALU per 16 bytes, a quarter of them
         // transcendental, next to a consumer wave that owns the SIMD's issue priority), so the per-item address math is
         // reduced to one add: item i of a thread is halo row i at a fixed column, offsets are base + i * row stride, row
         // validity is wave-uniform, and everything is branch-free (out-of-range offsets make loads return zero).
-        const int ptid = tid - 256, pw = wave - 4;
         if (CCN_DBG_BIT(a, 128)) __builtin_amdgcn_s_setprio(1);      // diagnostics: producer priority experiments
         if (CCN_DBG_BIT(a, 256)) __builtin_amdgcn_s_setprio(3);
-        const int ck = ptid & 7, pcol = ptid >> 3;                // 16-byte channel slice, halo column 0..31
-        // the two halo columns 32, 33 (HROWS rows x 8 slices = 160 units at 8 rows) go to threads 0..HROWS*16-1 as one more item
-        const int xrow = pcol >> 1, xcol = 32 + (pcol & 1);
-        const bool xthr = ptid < HROWS * 16;
-        constexpr int AIT = HROWS + 1;
-        u32x4 areg[AIT];
-        GnCoef<T> gk;
-        unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
-        bool colv = false, xv = false, x_vr = false;   // this thread's column / extra item inside the image; extra item reused
-        int rq_ti = 0, rq_c = 0;
-        // A request is split in two: prep() at the START of an iteration decodes the tile and fetches the GroupNorm
-        // coefficients of the chunk into a second register set; issue() after dump() sends the 11 input loads and adopts the
-        // coefficients.  (Fetched inside issue(), the coefficient loads made the wave wait a full L2 latency right there.)
-        GnCoef<T> gkn;
-        int q_b = 0, q_iy0 = 0, q_ix0 = 0, q_c = 0;
-        bool q_tv = false;
-        // in-kernel finalize (gstat): every producer wave reduces the partial sums of the sample it is about to stage by itself
-        // (no cross-wave step): lane l sums slots (l & 7), (l & 7) + 8, ... of group l >> 3 -- 8 groups x 8 lanes -- in fp64 and
-        // three xor-shuffles leave (mean, 1/sqrt(var + eps)) of group l >> 3 in every lane; a thread's 8 channels lie in one
-        // group (cpg % 8 == 0, checked on the host) whose statistics it fetches with a lane permute; gamma / beta of those
-        // channels are loaded raw in prep() and folded into (scale, shift) in issue(), one dump later, so nothing waits for them.
-        float st_mean = 0.f, st_rstd = 1.f, qn_mean = 0.f, qn_rstd = 1.f;
-        int st_b = -1;
-        f32x4 qn_g[2], qn_bt[2];
-        float2 sv[8];                            // one round of partial-sum loads (stats_issue -> stats_reduce)
-        auto stats_issue = [&](int b) __attribute__((always_inline)) {
-            const int g = lane >> 3, sub = lane & 7;
-            const int cpg = a.gs_cpg, pbn = a.gs_bn, pnt = a.gs_nnt;
-            const int jlo = (g * cpg) / pbn, jhi = ((g + 1) * cpg - 1) / pbn, nj = jhi - jlo + 1;
-            const int ne = a.gs_nsp * nj;                                  // <= 64 (host: in_kernel_stats)
-            const float2* const base = a.gs_part + (size_t)(b * 8 + g) * ((size_t)a.gs_nsp * pnt);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = sub + 8 * u;
-                sv[u] = make_float2(0.f, 0.f);
-                if (e < ne) {
-                    int sp = e, j = jlo;
-                    if (nj != 1) { sp = e / nj; j = jlo + (e - sp * nj); }
-                    sv[u] = base[(size_t)sp * pnt + j];
-                }
-            }
-        };
-        auto stats_reduce = [&]() __attribute__((always_inline)) {
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)sv[u].x; s2 += (double)sv[u].y; }
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-            const double mean = s1 * a.gs_inv_count;
-            double var = s2 * a.gs_inv_count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            st_mean = (float)mean;
-            st_rstd = __builtin_amdgcn_rsqf((float)(var + 1e-5));
-        };
-        // prep() = decode (tile / chunk of the next request) + coefficients; split so that the FIRST request of the kernel can put
-        // its input loads in front of the statistics' round trip (request_first below)
-        int q_cbs = 0; bool q_cv = false, q_cv_i = false;
-        bool q_skip = false, q_vr = false, d_skip = false, d_vr = false;      // wave-uniform; d_*: of the chunk whose loads are in areg
-        auto decode = [&]() __attribute__((always_inline)) -> bool {
-            const int v = vt(rq_ti);
-            if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
-                q_tv = rq_ti < my_tiles;
-                const int tile = vt_tile(q_tv ? v : vt(0));
-                const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
-                // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
-                const int tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
-                q_b = sp / (a.n_tx * a.n_ty);
-                q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
-                // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
-                // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
-                // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
-                // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
-                q_skip = a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0;
-                q_vr = TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0;
-            }
-            q_c = vt_kh(v) * nck + rq_c;
-            const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
-            q_cv = q_tv && cb < a.Cin;
-            q_cbs = q_cv ? cb : 0;
-            const bool fresh = gstat && rq_c == 0 && q_tv && q_b != st_b;  // wave-uniform: statistics of another sample needed
-            if (++rq_c == nck) { rq_c = 0; ++rq_ti; }
-            return fresh;
-        };
-        auto coef_loads = [&]() __attribute__((always_inline)) {
-            if (gstat) {
-                qn_g[0] = *(const f32x4*)(a.gs_gamma + q_cbs); qn_g[1] = *(const f32x4*)(a.gs_gamma + q_cbs + 4);
-                qn_bt[0] = *(const f32x4*)(a.gs_beta + q_cbs); qn_bt[1] = *(const f32x4*)(a.gs_beta + q_cbs + 4);
-            } else gkn.load(a.gn_ab + (size_t)q_b * a.Cin + q_cbs, gn && q_cv);
-        };
-        auto coef_sel = [&]() __attribute__((always_inline)) {
-            if (gstat) {
-                const int src = (q_cbs / a.gs_cpg) * 8;                    // a lane that holds the statistics of the channels' group
-                qn_mean = __shfl(st_mean, src); qn_rstd = __shfl(st_rstd, src);
-            }
-        };
-        auto prep = [&]() __attribute__((always_inline)) {
-            const bool fresh = decode();
-            coef_loads();
-            if (fresh) { stats_issue(q_b); stats_reduce(); st_b = q_b; }
-            coef_sel();
-        };
-        auto adopt = [&]() __attribute__((always_inline)) {
-            if (gstat) gk.from_raw(qn_g, qn_bt, qn_mean, qn_rstd, gn && q_cv_i);
-            else gk = gkn;
-        };
-        auto issue_loads = [&]() __attribute__((always_inline)) {
-            // (readfirstlane: these are wave-uniform by construction; saying so keeps the descriptor in SGPRs)
-            const int b = __builtin_amdgcn_readfirstlane(q_b), iy0 = __builtin_amdgcn_readfirstlane(q_iy0), ix0 = __builtin_amdgcn_readfirstlane(q_ix0);
-            const int cc = __builtin_amdgcn_readfirstlane(S2 ? q_c / 5 : q_c);     // channel chunk
-            const int pass = S2 ? q_c - cc * 5 : 0;
-            const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
-            const int cb = cc * CKE + ck * EPC;
-            const bool cv = q_tv && cb < a.Cin;
-            q_cv_i = cv;
-            d_skip = q_skip; d_vr = q_vr;
-            if (d_skip) return;                                                   // the chunk is in LDS already
-            // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
-            // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
-            // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
-            // per-row compare; only the column validity (and the channel tail) is per lane, ORed in as an out-of-range constant.
-            const unsigned img_bytes = (unsigned)(a.Hin * a.Win * a.Cin) * (unsigned)sizeof(T);
-            const unsigned coff = (unsigned)(((q_tv && cc * CKE < a.Cin) ? cc : 0) * CKE) * (unsigned)sizeof(T);
-            const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + (size_t)b * img_bytes + coff), 0, img_bytes - coff, 0x00020000);
-            const int rs = IS * a.Win * a.Cin * (int)sizeof(T);                   // row stride of the staged plane in bytes
-            const int ixr = IS * (ix0 + pcol) + px;                               // input column of this thread's halo column
-            colv = cv && ixr >= 0 && ixr < a.Win;
-            const unsigned cmask = colv ? 0u : OOB;
-            const int base = ((IS * iy0 + py) * a.Win + ixr) * a.Cin * (int)sizeof(T) + ck * 16;
-            // halo rows inside the image: [r_lo, r_hi) (wave-uniform), as a bit mask for the padding-stays-zero select in dump()
-            const int first = IS * iy0 + py;                                      // input row of halo row 0
-            const int r_lo = first < 0 ? (-first + IS - 1) / IS : 0;
-            int r_hi = (a.Hin - first + IS - 1) / IS; r_hi = r_hi > HROWS ? HROWS : (r_hi < 0 ? 0 : r_hi);
-            rowm = q_tv ? (((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u)) : 0u;
-#pragma unroll
-            for (int i = 0; i < HROWS; ++i) {
-                if (i < 2 && d_vr) continue;                                      // rows 0, 1 come from the previous tile's rows 8, 9
-                areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
-            }
-            {
-                const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
-                xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
-                x_vr = d_vr && xrow < 2;                                          // (columns 32, 33 of the reused rows)
-                const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
-                areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !x_vr) ? 0u : OOB), 0, 0);
-            }
-        };
-        auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
-        auto request = [&]() __attribute__((always_inline)) { prep(); issue(); };
-        // the kernel's first request: input loads go out BEFORE the wave waits for the partial sums (one memory round trip for
-        // everything the first dump needs instead of two)
-        auto request_first = [&]() __attribute__((always_inline)) {
-            const bool fresh = decode();
-            if (fresh) stats_issue(q_b);
-            coef_loads();
-            issue_loads();
-            if (fresh) { stats_reduce(); st_b = q_b; }
-            coef_sel();
-            adopt();
-        };
-        auto dump = [&](int buf) __attribute__((always_inline)) {
-            if (d_skip) return;
-            unsigned char* const As = smem + buf * L::A_BYTES;
-            int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
-            // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
-            // fragment address by a constant, which lets the consumers address all three dy taps with immediate offsets
-#pragma unroll
-            for (int i = 0; i < AIT; ++i) {
-                const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
-                const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
-                u32x4 v = areg[i];
-                if constexpr (TH == 8) {
-                    // vertical reuse: the finished (transformed) rows 8, 9 of the previous tile's same chunk sit in this buffer; this
-                    // thread's reads of them precede its own writes of the new rows 8, 9 below (program order, LDS in order per wave)
-                    if (i < 2 && d_vr) {
-                        *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = *(const u32x4*)(As + (px + 8 * HPITCH) * 128 + (((ck ^ sw) & 7) << 4));
-                        continue;
-                    }
-                    if (i == HROWS && d_vr) {
-                        // columns 32, 33: the copy is done by the thread that OWNS the source (halo rows 8, 9), right before it
-                        // overwrites it with the new tile's value -- a copy by the owner of rows 0, 1 would race with that write
-                        if (xthr && (pc >> 1) >= 8) *(u32x4*)(As + (px - 8 * HPITCH) * 128 + ((ck & 7) << 4)) = *(const u32x4*)(As + px * 128 + ((ck & 7) << 4));
-                        if (x_vr) continue;
-                    }
-                }
-                const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
-                if (gn) {
-                    const u32x4 tr = gk.template apply<true>(v);
-                    v = u32x4{0u, 0u, 0u, 0u};                                  // padding stays zero
-                    if (ok) v = tr;                                             // (exec-masked move: scalar ops instead of 4 selects)
-                }
-                if (i < HROWS || xthr) *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = v;
-                if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // bound the scheduler's appetite for registers
-            }
-        };
-
-        request_first();
-        dump(0);
+        request_first(0, HSPLIT, true);
+        dump(0, 0, HSPLIT, true);
         request();
         raw_barrier();                                             // chunk 0 visible
         stamp(1);
@@ -658,6 +670,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         }
         // staging address of this lane: pixel i*32 + r, channels 32*wave + g*8 + 4*h .. +3
         const int stg_lane = r * L::SP + (wave * 32 + 4 * h) * 2;
+        if constexpr (HSPLIT < HROWS) {
+            request_first(HSPLIT, HROWS, false);                   // the consumers' share of the first chunk (they are idle until it is staged)
+            dump(0, HSPLIT, HROWS, false);
+        }
         raw_barrier();                                             // chunk 0 visible
         stamp(1);
         int k = 0;
@@ -777,6 +793,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // staging address of this lane: pixel (wm*4 + i)*32 + r, channels wn*64 + j*32 + g*8 + 4*h .. +3
     const int stg_lane = (wm * 4 * 32 + r) * L::SP + (wn * 64 + 4 * h) * 2;
 
+    if constexpr (HSPLIT < HROWS) {
+        request_first(HSPLIT, HROWS, false);
+        dump(0, HSPLIT, HROWS, false);
+    }
     raw_barrier();                                                 // chunk 0 visible
     stamp(1);
     int k = 0;
