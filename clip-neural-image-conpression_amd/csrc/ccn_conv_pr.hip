@@ -15,17 +15,18 @@
 //     tile in LDS (32 ds_write_b64 per wave; the MFMA operands are swapped so a lane holds 4 consecutive channels of
 //     one pixel) and go straight on to the next tile.  The PRODUCER waves -- idle most of a chunk -- finish the
 //     previous tile during the next tile's first chunk: staging -> bias / FiLM / residual (rows prefetched into their
-//     registers one chunk earlier) -> 16-byte write-through NHWC stores, and the next GroupNorm's partial sums (the four
+//     registers one chunk earlier) -> 16-byte NHWC stores, and the next GroupNorm's partial sums (the four
 //     producer waves' per-channel sums are combined in LDS after the next barrier: ONE slot per tile).
 // Round 2 (what the stamps of a one-tile-per-CU launch showed: 5 us until the first chunk is visible, 4 us of tail, and a
 // 5 us finalize launch + kernel boundary in front of every conv):
 //   * the input GroupNorm's finalize is done here: every producer wave reduces the producer kernel's partial sums of the
 //     sample it is about to stage (<= 64 slots per group, one round of loads issued next to the first input loads);
-//   * the LAST tile's epilogue is split between the two roles (the consumers have nothing left to overlap it with) and its
+//   * the consumers, idle until the first chunk is in LDS, stage the lower half of its halo rows themselves; the LAST tile's
 //     bias / FiLM / residual operands are fetched before the final barrier of the chunk loop;
-//   * TH = 4: the same kernel on 4-row tiles for layers with fewer than #CUs 8-row tiles;
-//   * blocked tile order for 2-chunk layers, where chunk c of every tile lives in LDS buffer c: the four ConvTranspose
-//     parities of a spatial tile stage their input once, a 3x3 tile copies its two top halo rows from the tile above it.
+//   * TH = 4: the same kernel on 4-row tiles for layers with fewer than #CUs 8-row tiles.
+// Built, measured in product builds and compiled OUT (flags keep them reproducible): the last tile's epilogue split between the
+// two roles (-DCCN_AB_COOP_TAIL: +-1 % by box), write-through output stores (-DCCN_AB_SC1_STORES: -1..-2 %), blocked tile order
+// with staged input kept in LDS (-DCCN_LDS_REUSE: -3..-4 %, see CCN_REUSE below).
 // Tile: TH (8 or 4) rows x 32 pixels x 128 output channels, 4 consumer waves (3x3: all rows x 32 channels each; other tap sets:
 // 2x2 waves of 4x2 fragments of 32x32) + 4 producer waves.
 // Rounding: the conv accumulator is rounded to bf16 once before the affine/residual and the sum once more on store
@@ -35,6 +36,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+// Staged input kept in LDS between neighbouring tiles (blocked tile order; decode() in the kernel): measured in product builds on
+// one box as a NET LOSS -- 79.5 images/s without the code, 77.0 with it (its wave-uniform branches inside the producers' unrolled
+// load / stage loops cost more than the 20 % of staging it saves: with the code in place, switching the reuse on is worth +1.7 %,
+// having the code at all -5 %).  Kept behind -DCCN_LDS_REUSE for the record; the product build folds every use to false.
+#ifdef CCN_LDS_REUSE
+#define CCN_REUSE(x) (x)
+#else
+#define CCN_REUSE(x) false
+#endif
 
 namespace ccn {
 
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // Tile order of a workgroup: strided (vb, vb + grid, ...: at any moment the grid works on one contiguous band of tiles), or --
     // a.blocked_per > 0, chosen by launch_conv_pr for 2-chunk layers -- blocked (vb*per, vb*per + 1, ...), which makes a
     // workgroup's consecutive tiles NEIGHBOURS so that staged input can stay in LDS between them (a.reuse, see decode()).
-    const int per = a.blocked_per;
+    const int per = CCN_REUSE(true) ? a.blocked_per : 0;
     const int my_tiles = per > 0 ? min(per, ntiles - vb * per) : (ntiles - vb + grid - 1) / grid;      // >= 1 (host: grid <= ntiles, grid = ceil(ntiles / per))
     auto vt = [&](int ti) __attribute__((always_inline)) { return per > 0 ? vb * per + ti : vb + ti * grid; };
     const int ks = a.ksplit == 2 ? 2 : 1;
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int t2 = tile / a.n_nt;
         e_par = t2 % a.npar;
         const int sp = t2 / a.npar;
-        e_tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
+        e_tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
         e_b = sp / (a.n_tx * a.n_ty);
         const int nb = e_nt * BN + o16 * 8;
         const bool nvalid = nb < a.Cout;
@@ -206,7 +217,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (!CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt: read once (+0.6 %)
+                    #ifdef CCN_AB_PLAIN_RES
+    if (false) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);
+#else
+    if (!CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt: read once (+0.6 %)
+#endif
                         else dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
                     }
                 }
@@ -301,11 +316,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                         }
                     }
                 }
-                // Output stores are write-through (sc1): nothing is left dirty in the XCDs' L2s for the end-of-kernel release to
-                // write back before the next, dependent launch may start -- that flush cost every conv of a C2 forward 1.4-5 us
-                // (dirty bytes / ~6 TB/s): 74.3 -> 75.8 images/s; nt measured 75.4.  The split-K partial tile keeps plain stores
-                // (its reader is the partner workgroup on the same XCD, through that L2).  CCN_DBG=2048: plain stores (A/B).
+                // Plain (write-back) output stores.  Write-through (sc1) stores leave nothing dirty for the end-of-kernel release to
+                // flush and looked 2 % faster in the diagnostics build; in product builds they are 1-2 % SLOWER on every box tried
+                // (the next conv then reads its input from beyond L2), so they stay behind -DCCN_AB_SC1_STORES.
+#ifndef CCN_AB_SC1_STORES
+                if (true) __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
+#else
                 if (first || CCN_DBG_BIT(a, 2048)) __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
+#endif
                 else __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 16);
                 if (live) {                                           // exec-masked: costs scalar ops, not 8 VALU multiplies
 #pragma unroll
@@ -366,10 +384,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         }
     };
 
-    // The last tile of the launch: its epilogue overlaps nothing (the consumers are done), so both roles run half of it each --
-    // producers the first TH/2 rows, consumers the rest -- and meet at one more barrier for the statistics.  Not under split-K
-    // (its hand-off flags are per producer wave).
+    // The last tile of the launch: its epilogue overlaps nothing (the consumers are done), so both roles CAN run half of it each --
+    // producers the first TH/2 rows, consumers the rest -- and meet at one more barrier for the statistics (not under split-K: its
+    // hand-off flags are per producer wave).  Measured +0.5 % on one box, -1.3 % on another, 0 on a third: off in the product build.
+#ifndef CCN_AB_COOP_TAIL
+    const bool coop_tail = false;
+#else
     const bool coop_tail = ks == 1 && !CCN_DBG_BIT(a, 1024);
+#endif
 
     // ---- input staging machinery (role-neutral like the epilogue's: the producers run it for every chunk; the consumers,
     // idle until the first chunk is in LDS, stage the lower half of the halo rows of that first chunk themselves)
@@ -439,15 +461,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int tile = vt_tile(q_tv ? v : vt(0));
             const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
             // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
-            const int tx = a.reuse == 2 ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = a.reuse == 2 ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
+            const int tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
             // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
             // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
             // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
             // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
-            q_skip = a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0;
-            q_vr = TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0;
+            q_skip = CCN_REUSE(a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0);
+            q_vr = CCN_REUSE(TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0);
         }
         q_c = vt_kh(v) * nck + rq_c;
         const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
@@ -490,7 +512,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const bool cv = q_tv && cb < a.Cin;
         q_cv_i = cv;
         d_skip = q_skip; d_vr = q_vr;
-        if (d_skip) return;                                                   // the chunk is in LDS already
+        if (CCN_REUSE(d_skip)) return;                                        // the chunk is in LDS already
         // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
         // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
         // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
@@ -511,15 +533,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
         for (int i = 0; i < HROWS; ++i) {
             if (i < r0 || i >= r1) continue;
-            if (i < 2 && d_vr) continue;                                      // rows 0, 1 come from the previous tile's rows 8, 9
+            if (i < 2 && CCN_REUSE(d_vr)) continue;                           // rows 0, 1 come from the previous tile's rows 8, 9
             areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
         }
         {
             const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
             xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
-            x_vr = d_vr && xrow < 2;                                          // (columns 32, 33 of the reused rows)
+            x_vr = CCN_REUSE(d_vr && xrow < 2);                               // (columns 32, 33 of the reused rows)
             const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
-            if (with_x) areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !x_vr) ? 0u : OOB), 0, 0);
+            if (with_x) areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !CCN_REUSE(x_vr)) ? 0u : OOB), 0, 0);
         }
     };
     auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         adopt();
     };
     auto dump = [&](int buf, int r0 = 0, int r1 = TH + 2, bool with_x = true) __attribute__((always_inline)) {
-        if (d_skip) return;
+        if (CCN_REUSE(d_skip)) return;
         unsigned char* const As = smem + buf * L::A_BYTES;
         int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
         // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
@@ -550,15 +572,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             if constexpr (TH == 8) {
                 // vertical reuse: the finished (transformed) rows 8, 9 of the previous tile's same chunk sit in this buffer; this
                 // thread's reads of them precede its own writes of the new rows 8, 9 below (program order, LDS in order per wave)
-                if (i < 2 && d_vr) {
+                if (i < 2 && CCN_REUSE(d_vr)) {
                     *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = *(const u32x4*)(As + (px + 8 * HPITCH) * 128 + (((ck ^ sw) & 7) << 4));
                     continue;
                 }
-                if (i == HROWS && d_vr) {
+                if (i == HROWS && CCN_REUSE(d_vr)) {
                     // columns 32, 33: the copy is done by the thread that OWNS the source (halo rows 8, 9), right before it
                     // overwrites it with the new tile's value -- a copy by the owner of rows 0, 1 would race with that write
                     if (xthr && (pc >> 1) >= 8) *(u32x4*)(As + (px - 8 * HPITCH) * 128 + ((ck & 7) << 4)) = *(const u32x4*)(As + px * 128 + ((ck & 7) << 4));
-                    if (x_vr) continue;
+                    if (CCN_REUSE(x_vr)) continue;
                 }
             }
             const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
@@ -990,10 +1012,10 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // tiles.  ConvTranspose: the four parities of a spatial tile (consecutive tile ids) share their staged input; 3x3 s1: a tile
     // reuses the two bottom halo rows of the tile above it.
     d.blocked_per = 0; d.reuse = 0;
-#ifdef CCN_NO_REUSE
-    static const bool no_reuse = true;                                        // A/B build (make ab EXTRA=-DCCN_NO_REUSE)
-#else
+#ifdef CCN_LDS_REUSE
     static const bool no_reuse = diag_env("CCN_NO_REUSE") != nullptr;
+#else
+    static const bool no_reuse = true;                                        // product build: see CCN_REUSE at the top of this file
 #endif
     if (!no_reuse && ks == 1 && a.n_nt == 1 && a.nchunk == 2 && ntiles > grid && (ct || (c3 && a.th == 8 && a.n_ty > 1))) {
         const int per = (ntiles + grid - 1) / grid;

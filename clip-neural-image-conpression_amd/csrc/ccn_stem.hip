@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
             const int idx = it * 64 + lane, pxl = idx / SL, sl = idx - pxl * SL;
             const u32x4 v16 = *(const u32x4*)(strip + pxl * TRP + sl * 16);
             const bool ok = x0 + pxl < W && sl * 8 < C;
-            // write-through (sc1): no dirty L2 lines for the end-of-kernel release to flush (see ccn_conv_pr.hip)
-            __builtin_amdgcn_raw_buffer_store_b128(v16, osrd, ok ? (unsigned)(((b * H + y) * W + x0 + pxl) * C + sl * 8) * 2u : OOB, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v16, osrd, ok ? (unsigned)(((b * H + y) * W + x0 + pxl) * C + sl * 8) * 2u : OOB, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // strip read before the next unit rewrites it
     }
