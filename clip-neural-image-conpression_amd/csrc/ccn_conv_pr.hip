@@ -607,6 +607,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // transcendental, next to a consumer wave that owns the SIMD's issue priority), so the per-item address math is
         // reduced to one add: item i of a thread is halo row i at a fixed column, offsets are base + i * row stride, row
         // validity is wave-uniform, and everything is branch-free (out-of-range offsets make loads return zero).
+#ifdef CCN_AB_PPRIO
+        __builtin_amdgcn_s_setprio(CCN_AB_PPRIO);                    // A/B build: static producer priority
+#endif
+        // the producers outrank the consumers (priority 2) where THEY are the pole (launch_conv_pr decides per layer)
+        if (a.prod_first) __builtin_amdgcn_s_setprio(3);
         if (CCN_DBG_BIT(a, 128)) __builtin_amdgcn_s_setprio(1);      // diagnostics: producer priority experiments
         if (CCN_DBG_BIT(a, 256)) __builtin_amdgcn_s_setprio(3);
         request_first(0, HSPLIT, true);
@@ -653,7 +658,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     }
 
     // ---------------------------------------------------------------------- consumers (4 waves)
+#ifndef CCN_AB_NO_CPRIO
     if (!CCN_DBG_BIT(a, 16)) __builtin_amdgcn_s_setprio(2);
+#endif
     if constexpr (NTAPS == 9 && COLW) {
         // 3x3, column-per-wave form: wave w owns ALL 8 tile rows of the 32 output channels nt*128 + 32w.  Per (dx, k-slice)
         // group it needs 3 weight fragments (one per dy) -- half the L1 traffic of the 4x2 form, whose row pairs fetched the
@@ -1012,6 +1019,14 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // tiles.  ConvTranspose: the four parities of a spatial tile (consecutive tile ids) share their staged input; 3x3 s1: a tile
     // reuses the two bottom halo rows of the tile above it.
     d.blocked_per = 0; d.reuse = 0;
+    // Producer waves outrank the consumers on the 2-chunk 3x3 layers (the 128-channel levels, where the producers are the pole and
+    // the consumers wait a quarter of their time at barriers): +0.8 % on two boxes in product builds; on every layer: -0.5..+1.7 %
+    // by box; on the deep-K layers only: 0.  (-DCCN_AB_PF_NONE: consumers first everywhere, the round-1 setting.)
+#if defined(CCN_AB_PF_NONE)
+    d.prod_first = 0;
+#else
+    d.prod_first = (a.nchunk <= 2 && c3) ? 1 : 0;
+#endif
 #ifdef CCN_LDS_REUSE
     static const bool no_reuse = diag_env("CCN_NO_REUSE") != nullptr;
 #else
