@@ -119,7 +119,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // Tile order of a workgroup: strided (vb, vb + grid, ...: at any moment the grid works on one contiguous band of tiles), or --
     // a.blocked_per > 0, chosen by launch_conv_pr for 2-chunk layers -- blocked (vb*per, vb*per + 1, ...), which makes a
     // workgroup's consecutive tiles NEIGHBOURS so that staged input can stay in LDS between them (a.reuse, see decode()).
+#ifdef CCN_AB_BLOCKED
+    const int per = a.blocked_per;                                 // A/B build: blocked tile order alone (no kept input)
+#else
     const int per = CCN_REUSE(true) ? a.blocked_per : 0;
+#endif
     const int my_tiles = per > 0 ? min(per, ntiles - vb * per) : (ntiles - vb + grid - 1) / grid;      // >= 1 (host: grid <= ntiles, grid = ceil(ntiles / per))
     auto vt = [&](int ti) __attribute__((always_inline)) { return per > 0 ? vb * per + ti : vb + ti * grid; };
     const int ks = a.ksplit == 2 ? 2 : 1;
@@ -666,8 +670,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // group it needs 3 weight fragments (one per dy) -- half the L1 traffic of the 4x2 form, whose row pairs fetched the
         // same weights twice -- and the 10 halo rows of that column/slice, each read ONCE from LDS and used for up to three
         // (output row, dy) pairs the moment it arrives (row hh feeds output rows hh, hh-1, hh-2), so only the prefetch window is live.
-        constexpr int WIN = 6, PF = 4;                             // row-fragment window / prefetch distance (rows)
-        constexpr int DG = 3;                                      // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
+#ifndef CCN_AB_PF
+#define CCN_AB_PF 4
+#endif
+#ifndef CCN_AB_DG
+#define CCN_AB_DG 3
+#endif
+        constexpr int WIN = 6, PF = CCN_AB_PF;                     // row-fragment window / prefetch distance (rows)
+        constexpr int DG = CCN_AB_DG;                              // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
         constexpr int NG = 12, NROW = HROWS;
 #ifdef CCN_WLOAD_AT0
         constexpr bool WLOAD_AT0 = true;
@@ -1027,7 +1037,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
 #else
     d.prod_first = (a.nchunk <= 2 && c3) ? 1 : 0;
 #endif
-#ifdef CCN_LDS_REUSE
+#if defined(CCN_LDS_REUSE) || defined(CCN_AB_BLOCKED)
     static const bool no_reuse = diag_env("CCN_NO_REUSE") != nullptr;
 #else
     static const bool no_reuse = true;                                        // product build: see CCN_REUSE at the top of this file
