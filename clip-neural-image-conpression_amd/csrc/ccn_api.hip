@@ -476,7 +476,7 @@ struct PlanBuilder {
         if (s2pr) { g.th = 8; g.n_ty = ceil_div(g.MH, 8); }
         // small layers (at most #CUs/2 tiles of 8 rows: the 32-pixel level at C2): 8-row tiles on the persistent kernel with the
         // Cin chunks split over two workgroups per tile instead of 4-row tiles on the LDS-bound kernel
-        const int ksplit = split_k_for(cw, g, gn_ab != nullptr, s2pr);
+        const int ksplit = res ? 1 : split_k_for(cw, g, gn_ab != nullptr, s2pr);      // (the split-K instantiation has no residual path of its own)
         if (ksplit == 2 && g.th != 8) { g.th = 8; g.n_ty = ceil_div(g.MH, 8); }
         std::shared_ptr<ConvArgs> ap(new ConvArgs());
         ConvArgs& a = *ap;

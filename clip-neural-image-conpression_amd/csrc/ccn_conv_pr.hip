@@ -79,7 +79,9 @@ static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 // level at C2: 128 -> 256 tiles) -- every CU gets a tile without splitting K (no hand-off between workgroups), the producers
 // stage 6 halo rows instead of 10, a consumer wave owns 4 rows x 32 channels (12 MFMAs per (dx, k-slice) group per 3 weight
 // fragments: twice the weight stream per MFMA of the 8-row form, still from L2).
-template <int NTAPS, int D, int MODE, int TH = 8>
+// GS: how the input's GroupNorm reaches the kernel -- 0 the finalized scale / shift table (a.gn_ab), 1 formed here from the producer
+// kernel's partial sums (a.gs_part), 2 none (the input is already activated, or the form has no GroupNorm: ConvTranspose, stride 2).
+template <int NTAPS, int D, int MODE, int TH = 8, int GS = 0>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
     static_assert(TH == 8 || (TH == 4 && NTAPS == 9), "4-row tiles: 3x3 stride-1 form only");
@@ -90,6 +92,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     constexpr int MF = 4, NF = 2;
     constexpr int BN = 128;
     constexpr int HROWS = TH + 2;
+    // output stride / parities of the form (launch_conv_pr checks a.OS / a.npar against them): compile-time, so the tile decodes and
+    // the epilogue's address arithmetic fold for the 3x3 forms
+    constexpr int OSC = NTAPS == 4 ? 2 : 1, NPARC = NTAPS == 4 ? 4 : 1;
     constexpr int EPC = 8, CKE = 64;
     constexpr int NSTEP = NTAPS * 4;                           // step = tap * 4 + kk (one 16-byte K slice per lane half)
     // NTAPS == 2: the stride-2 3x3 conv.  Its 9 taps fall on the four parity planes P[py][px](i, j) = in(2i+py, 2j+px) of the
@@ -126,7 +131,13 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #endif
     const int my_tiles = per > 0 ? min(per, ntiles - vb * per) : (ntiles - vb + grid - 1) / grid;      // >= 1 (host: grid <= ntiles, grid = ceil(ntiles / per))
     auto vt = [&](int ti) __attribute__((always_inline)) { return per > 0 ? vb * per + ti : vb + ti * grid; };
+    // split-K launches run the MODE 2 instantiation only (launch_conv_pr): everywhere else ks folds to 1 at compile time and the
+    // hand-off branches of the epilogue disappear
+#ifdef CCN_AB_RUNTIME_KS
     const int ks = a.ksplit == 2 ? 2 : 1;
+#else
+    const int ks = (MODE == 2 && a.ksplit == 2) ? 2 : 1;
+#endif
     const int nck = a.nchunk / ks;                             // chunks per virtual tile
     const int ktotal = my_tiles * nck;
     auto vt_tile = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v >> 1) : v; };
@@ -135,8 +146,24 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const unsigned char* const inb = (const unsigned char*)a.in;
     // GroupNorm of the input: scale/shift per (sample, channel) either from the table a separate finalize launch wrote (gn_ab),
     // or -- gs_part != null -- formed HERE from the producing kernel's partial sums (no finalize launch between two convs)
+#ifdef CCN_AB_RUNTIME_GS
     const bool gstat = NTAPS == 9 && MODE != 2 && a.gs_part != nullptr;       // (3x3 stride-1 layers without split-K only)
+#else
+    constexpr bool gstat = GS == 1;                                           // (launch_conv_pr: GS == 1 exactly when a.gs_part is set)
+    static_assert(GS != 1 || (NTAPS == 9 && MODE != 2), "in-kernel statistics: 3x3 stride-1 layers without split-K");
+#endif
+    // (the ConvTranspose / stride-2 forms never have a GroupNorm on their input -- launch_conv_pr refuses it -- so the transform and
+    // its coefficient traffic compile out of those instantiations)
+#ifdef CCN_AB_RUNTIME_GN
     const bool gn = (a.gn_ab != nullptr || gstat) && !CCN_DBG_BIT(a, 32);     // CCN_DBG=32: skip the transform (timing experiments only)
+#else
+#ifdef CCN_AB_RUNTIME_GS
+    const bool gn = NTAPS == 9 && (a.gn_ab != nullptr || gstat) && !CCN_DBG_BIT(a, 32);
+#else
+    // GS: 0 = scale / shift table (a.gn_ab), 1 = formed here from partial sums, 2 = no GroupNorm on the input (pre-activated input)
+    const bool gn = NTAPS == 9 && GS != 2 && !CCN_DBG_BIT(a, 32);
+#endif
+#endif
     constexpr unsigned OOB = 0x7FFFFFF0u;
     auto raw_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // laundered copy of e_base: otherwise the 16 offsets are computed once per tile and kept live across dump() and the barrier
     auto item_off = [&](unsigned eb, int it) __attribute__((always_inline)) -> unsigned {
         const unsigned rmask = (it >> 1) < e_rows ? 0u : OOB;                 // wave-uniform
-        return (eb + (unsigned)(it >> 1) * (unsigned)(a.OS * a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(a.OS * a.Cout * (int)sizeof(T)))
+        return (eb + (unsigned)(it >> 1) * (unsigned)(OSC * a.Wout * a.Cout * (int)sizeof(T)) + (unsigned)((it & 1) * 16) * (unsigned)(OSC * a.Cout * (int)sizeof(T)))
                | ((it & 1) ? e_m1 : e_m0) | rmask;
     };
     // during the tile's last chunk: decode the tile
@@ -196,14 +223,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         e_kh = vt_kh(v); e_tile = tile;
         e_nt = tile % a.n_nt;
         const int t2 = tile / a.n_nt;
-        e_par = t2 % a.npar;
-        const int sp = t2 / a.npar;
+        e_par = t2 % NPARC;
+        const int sp = t2 / NPARC;
         e_tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
         e_b = sp / (a.n_tx * a.n_ty);
         const int nb = e_nt * BN + o16 * 8;
         const bool nvalid = nb < a.Cout;
         // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
-        e_base = (unsigned)(((e_b * a.Hout + e_ty * TH * a.OS + (e_par >> 1)) * a.Wout + (e_tx * 32 + pr) * a.OS + (e_par & 1)) * a.Cout + nb) * (unsigned)sizeof(T);
+        e_base = (unsigned)(((e_b * a.Hout + e_ty * TH * OSC + (e_par >> 1)) * a.Wout + (e_tx * 32 + pr) * OSC + (e_par & 1)) * a.Cout + nb) * (unsigned)sizeof(T);
         e_rows = a.MH - e_ty * TH;
         e_m0 = (nvalid && e_tx * 32 + pr < a.MW) ? 0u : OOB;
         e_m1 = (nvalid && e_tx * 32 + pr + 16 < a.MW) ? 0u : OOB;
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             }
             // the four waves' per-channel sums are combined into ONE slot per tile after the next workgroup barrier (combine())
             pd_on = true; pd_b = e_b; pd_n0 = e_nt * BN;
-            pd_slot = ((e_ty * a.n_tx + e_tx) * a.npar + e_par) * a.n_nt + e_nt;
+            pd_slot = ((e_ty * a.n_tx + e_tx) * NPARC + e_par) * a.n_nt + e_nt;
         }
     };
     // After the barrier that follows an epilogue: group sums over the four producer waves' per-channel sums, one slot per
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
             q_tv = rq_ti < my_tiles;
             const int tile = vt_tile(q_tv ? v : vt(0));
-            const int sp = tile / (a.n_nt * a.npar);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+            const int sp = tile / (a.n_nt * NPARC);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
             // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
             const int tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
@@ -472,7 +499,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
             // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
             // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
-            q_skip = CCN_REUSE(a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % a.npar != 0);
+            q_skip = CCN_REUSE(a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % NPARC != 0);
             q_vr = CCN_REUSE(TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0);
         }
         q_c = vt_kh(v) * nck + rq_c;
@@ -814,11 +841,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // weight fragments: [chunk][Cout_pad/32][tap][kk][lane] x 16 B (host-packed); this wave owns columns nt*4 + wn*2 + {0,1}
     const int n32 = a.Cout_pad / 32;
     constexpr unsigned COLB = NSTEP * 1024;                        // bytes of one 32-channel column of one chunk
-    const unsigned wtotal = (unsigned)((size_t)a.npar * a.nchunk * n32 * COLB);
+    const unsigned wtotal = (unsigned)((size_t)NPARC * a.nchunk * n32 * COLB);
     const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
-        const int nt = tile % a.n_nt, par = (tile / a.n_nt) % a.npar;      // ConvTranspose: [parity][chunk][column][tap][kk][lane]
+        const int nt = tile % a.n_nt, par = (tile / a.n_nt) % NPARC;      // ConvTranspose: [parity][chunk][column][tap][kk][lane]
         return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((par * a.nchunk + chunk) * n32 + nt * 4 + wn * NF) * COLB));
     };
     u32x4 bq[D][NF];
@@ -844,7 +871,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
         int toffs[NTAPS == 9 ? 1 : NTAPS], tdxs[NTAPS == 9 ? 1 : NTAPS];   // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
-            const int par = (tile / a.n_nt) % a.npar;
+            const int par = (tile / a.n_nt) % NPARC;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) { tdxs[t] = a.tapinfo_dx(par * 4 + t); toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + tdxs[t]; }
         }
@@ -957,8 +984,18 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #define PR_D 6
 #endif
 typedef void (*pr_fn_t)(const ConvArgs, int);
-static pr_fn_t pick_pr(int ntaps, int mode, int th = 8)
+static pr_fn_t pick_pr(int ntaps, int mode, int th = 8, int gs = 0)
 {
+#ifndef CCN_AB_RUNTIME_GS
+    if (gs == 1 && ntaps == 9 && mode != 2) {
+        if (th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4, 1>;
+        return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 8, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 8, 1>;
+    }
+    if (gs == 2 && ntaps == 9) {
+        if (th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4, 2> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 4, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4, 2>);
+        return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 8, 2> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 8, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 8, 2>);
+    }
+#endif
     if (ntaps == 9 && th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 4> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4>);
     if (ntaps == 9) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0>);
     if (ntaps == 2) return mode == 1 ? (pr_fn_t)conv_pr_kernel<2, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<2, 8, 2> : (pr_fn_t)conv_pr_kernel<2, 8, 0>);
@@ -983,6 +1020,14 @@ hipError_t conv_pr_prepare()
         e = hipFuncSetAttribute((const void*)pick_pr(9, mode, 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLdsT<4>::TOTAL);
         if (e != hipSuccess) return e;
     }
+    for (int gs = 1; gs <= 2; ++gs)
+        for (int mode = 0; mode < 3; ++mode) {
+            if (gs == 1 && mode == 2) continue;
+            e = hipFuncSetAttribute((const void*)pick_pr(9, mode, 8, gs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)pick_pr(9, mode, 4, gs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLdsT<4>::TOTAL);
+            if (e != hipSuccess) return e;
+        }
     int dev = 0;
     e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1013,9 +1058,10 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // a.ntaps as the persistent kernel sees the layer: 9 (3x3 s1), 4 (ConvTranspose parity), 2 (3x3 s2 as plane passes, nchunk = 5 x channel chunks)
     const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
     const bool s2 = a.ntaps == 2 && a.npar == 1 && a.OS == 1 && !a.gn_ab && (a.nchunk % 5) == 0;
+    if ((ct || s2) && (a.gn_ab || a.gs_part)) return hipErrorInvalidValue;     // (no input GroupNorm in those forms)
     if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || !(a.th == 8 || (a.th == 4 && c3)) || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
     const int ks = a.ksplit == 2 ? 2 : 1;
-    if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5))) return hipErrorInvalidValue;
+    if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5) || a.res)) return hipErrorInvalidValue;   // (split-K: MODE 2, no residual)
     const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt * ks;
     static const int cap = diag_env("CCN_PR_GRID") ? atoi(diag_env("CCN_PR_GRID")) : 0;       // diagnostics build only
     int grid = cap > 0 ? cap : (g_cus > 0 ? g_cus : 256);
@@ -1055,7 +1101,8 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
         g_stamp_grid = (unsigned)grid;
         d.stamps = g_stamps;
     } else d.stamps = nullptr;
-    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res ? 1 : (ks == 2 ? 2 : 0), a.th), dim3((unsigned)grid), dim3(512),
+    if (a.gs_part && !(c3 && ks == 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pick_pr(a.ntaps, a.res ? 1 : (ks == 2 ? 2 : 0), a.th, a.gs_part ? 1 : (a.gn_ab ? 0 : 2)), dim3((unsigned)grid), dim3(512),
                        a.th == 4 ? PrLdsT<4>::TOTAL : PrLds::TOTAL, s, d, ntiles);
     return hipGetLastError();
 }
