@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 // Staged input kept in LDS between neighbouring tiles (blocked tile order; decode() in the kernel): measured in product builds on
 // one box as a NET LOSS -- 79.5 images/s without the code, 77.0 with it (its wave-uniform branches inside the producers' unrolled
@@ -50,6 +51,15 @@
 namespace ccn {
 
 namespace {
+
+// x / d for a divisor known at launch: d's magic number m = ceil(2^32 / d) comes in the launch arguments (0 for d == 1), the quotient
+// is one v_mul_hi_u32 instead of the ~40-instruction float-reciprocal sequence of a runtime integer division -- a tile decode has five
+// of them and the producers, the pole of the 128-channel layers, decode two tiles' worth per tile.  Exact while x * d < 2^32.
+#ifdef CCN_AB_SLOW_DIV
+#define CCN_FDIV(x, m, d) ((int)(x) / (int)(d))
+#else
+#define CCN_FDIV(x, m, d) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))
+#endif
 
 template <int TH_> struct PrLdsT {
     static constexpr int HROWS = TH_ + 2, HPITCH = 34;
@@ -221,12 +231,21 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto epi_setup = [&](int v) __attribute__((always_inline)) {
         const int tile = vt_tile(v);
         e_kh = vt_kh(v); e_tile = tile;
-        e_nt = tile % a.n_nt;
-        const int t2 = tile / a.n_nt;
+        const int t2 = CCN_FDIV(tile, a.fd_nt, a.n_nt);
+        e_nt = tile - t2 * a.n_nt;
         e_par = t2 % NPARC;
         const int sp = t2 / NPARC;
+#ifdef CCN_LDS_REUSE
         e_tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
         e_b = sp / (a.n_tx * a.n_ty);
+#else
+        {
+            const int row = CCN_FDIV(sp, a.fd_tx, a.n_tx);                    // (b, ty) row of tiles
+            e_tx = sp - row * a.n_tx;
+            e_b = CCN_FDIV(sp, a.fd_sp, a.n_tx * a.n_ty);
+            e_ty = row - e_b * a.n_ty;
+        }
+#endif
         const int nb = e_nt * BN + o16 * 8;
         const bool nvalid = nb < a.Cout;
         // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
@@ -399,8 +418,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int n0 = pd_n0;
         if (n0 >= a.Cout) return;
         const int nend = min(n0 + BN, a.Cout);
-        const int g1 = (nend - 1) / a.cpg;
-        for (int g = n0 / a.cpg + ew; g <= g1; g += 4) {
+        const int g1 = CCN_FDIV(nend - 1, a.fd_cpg, a.cpg);
+        for (int g = CCN_FDIV(n0, a.fd_cpg, a.cpg) + ew; g <= g1; g += 4) {
             const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
             float t1 = 0.f, t2 = 0.f;
             const float* const wa = all + (lane >> 4) * 256;
@@ -490,10 +509,17 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
             q_tv = rq_ti < my_tiles;
             const int tile = vt_tile(q_tv ? v : vt(0));
-            const int sp = tile / (a.n_nt * NPARC);                   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+            const int sp = CCN_FDIV(tile, a.fd_ntp, a.n_nt * NPARC);   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
+#ifdef CCN_LDS_REUSE
             // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
             const int tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
             q_b = sp / (a.n_tx * a.n_ty);
+#else
+            const int row = CCN_FDIV(sp, a.fd_tx, a.n_tx);
+            const int tx = sp - row * a.n_tx;
+            q_b = CCN_FDIV(sp, a.fd_sp, a.n_tx * a.n_ty);
+            const int ty = row - q_b * a.n_ty;
+#endif
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
             // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
             // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
     auto coef_sel = [&]() __attribute__((always_inline)) {
         if (gstat) {
-            const int src = (q_cbs / a.gs_cpg) * 8;                    // a lane that holds the statistics of the channels' group
+            const int src = CCN_FDIV(q_cbs, a.fd_gscpg, a.gs_cpg) * 8; // a lane that holds the statistics of the channels' group
             qn_mean = __shfl(st_mean, src); qn_rstd = __shfl(st_rstd, src);
         }
     };
@@ -719,7 +745,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
         const unsigned lane16 = (unsigned)lane * 16u;
         auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
-            const int nt = tile % a.n_nt;
+            const int nt = tile - CCN_FDIV(tile, a.fd_nt, a.n_nt) * a.n_nt;
             return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(chunk * n32 + nt * 4 + wave) * COLB));
         };
         auto rbase = [&](int row_lin, int hx) __attribute__((always_inline)) { return row_lin * 128 + (((hx >> 1) & 6) << 4) + (((h ^ (hx >> 1)) & 1) << 4); };
@@ -845,7 +871,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.wfrag, 0, wtotal, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto wbase_of = [&](int tile, int chunk) __attribute__((always_inline)) -> unsigned {
-        const int nt = tile % a.n_nt, par = (tile / a.n_nt) % NPARC;      // ConvTranspose: [parity][chunk][column][tap][kk][lane]
+        const int t2 = CCN_FDIV(tile, a.fd_nt, a.n_nt);
+        const int nt = tile - t2 * a.n_nt, par = t2 % NPARC;               // ConvTranspose: [parity][chunk][column][tap][kk][lane]
         return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((par * a.nchunk + chunk) * n32 + nt * 4 + wn * NF) * COLB));
     };
     u32x4 bq[D][NF];
@@ -871,7 +898,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
         int toffs[NTAPS == 9 ? 1 : NTAPS], tdxs[NTAPS == 9 ? 1 : NTAPS];   // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
-            const int par = (tile / a.n_nt) % NPARC;
+            const int par = CCN_FDIV(tile, a.fd_nt, a.n_nt) % NPARC;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) { tdxs[t] = a.tapinfo_dx(par * 4 + t); toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + tdxs[t]; }
         }
@@ -1075,6 +1102,13 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // tiles.  ConvTranspose: the four parities of a spatial tile (consecutive tile ids) share their staged input; 3x3 s1: a tile
     // reuses the two bottom halo rows of the tile above it.
     d.blocked_per = 0; d.reuse = 0;
+    {
+        auto magic = [](long dv) -> unsigned { return dv <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)dv - 1) / (unsigned long long)dv); };
+        const long dmax = std::max<long>(std::max<long>((long)a.n_nt * a.npar, (long)a.n_tx * a.n_ty), std::max<long>(a.cpg, a.gs_cpg));
+        if ((unsigned long long)std::max<long>(ntiles, 8192) * (unsigned long long)dmax >= 0x100000000ull) return hipErrorInvalidValue;   // CCN_FDIV exactness
+        d.fd_nt = magic(a.n_nt); d.fd_ntp = magic((long)a.n_nt * a.npar); d.fd_tx = magic(a.n_tx); d.fd_sp = magic((long)a.n_tx * a.n_ty);
+        d.fd_cpg = magic(a.cpg); d.fd_gscpg = magic(a.gs_cpg);
+    }
     // Producer waves outrank the consumers on the 2-chunk 3x3 layers (the 128-channel levels, where the producers are the pole and
     // the consumers wait a quarter of their time at barriers): +0.8 % on two boxes in product builds; on every layer: -0.5..+1.7 %
     // by box; on the deep-K layers only: 0.  (-DCCN_AB_PF_NONE: consumers first everywhere, the round-1 setting.)
