@@ -470,28 +470,32 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     float st_mean = 0.f, st_rstd = 1.f, qn_mean = 0.f, qn_rstd = 1.f;
     int st_b = -1;
     f32x4 qn_g[2], qn_bt[2];
+    unsigned svmask = 0u;                    // valid slots of sv[]
     float2 sv[8];                            // one round of partial-sum loads (stats_issue -> stats_reduce)
     auto stats_issue = [&](int b) __attribute__((always_inline)) {
+        // branch-free: the eight loads leave back to back (a per-slot `if` made the compiler wait for each load in its own block,
+        // eight serial round trips on the cold-start path); slots past the group's count read slot 0 and are masked in stats_reduce
         const int g = lane >> 3, sub = lane & 7;
-        const int cpg = a.gs_cpg, pbn = a.gs_bn, pnt = a.gs_nnt;
-        const int jlo = (g * cpg) / pbn, jhi = ((g + 1) * cpg - 1) / pbn, nj = jhi - jlo + 1;
-        const int ne = a.gs_nsp * nj;                                  // <= 64 (host: in_kernel_stats)
-        const float2* const base = a.gs_part + (size_t)(b * 8 + g) * ((size_t)a.gs_nsp * pnt);
+        const int cpg = a.gs_cpg, pnt = a.gs_nnt, nsp = a.gs_nsp;
+        const int jlo = CCN_FDIV(g * cpg, a.fd_gsbn, a.gs_bn), jhi = CCN_FDIV((g + 1) * cpg - 1, a.fd_gsbn, a.gs_bn), nj = jhi - jlo + 1;
+        const float2* const base = a.gs_part + (size_t)(b * 8 + g) * ((size_t)nsp * pnt) + jlo;   // nsp * nj <= 64 (host: in_kernel_stats)
+        int off[8];
+        svmask = 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = sub + 8 * u;
-            sv[u] = make_float2(0.f, 0.f);
-            if (e < ne) {
-                int sp = e, j = jlo;
-                if (nj != 1) { sp = e / nj; j = jlo + (e - sp * nj); }
-                sv[u] = base[(size_t)sp * pnt + j];
-            }
+            const int e = sub + 8 * u;                                 // slot e = jj * nsp + sp
+            const int jj = CCN_FDIV(e, a.fd_gsnsp, nsp), sp = e - jj * nsp;
+            const bool ok = jj < nj;
+            off[u] = ok ? sp * pnt + jj : 0;
+            svmask |= ok ? (1u << u) : 0u;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = base[off[u]];
     };
     auto stats_reduce = [&]() __attribute__((always_inline)) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += (double)sv[u].x; s2 += (double)sv[u].y; }
+        for (int u = 0; u < 8; ++u) { const bool ok = (svmask >> u) & 1u; s1 += ok ? (double)sv[u].x : 0.0; s2 += ok ? (double)sv[u].y : 0.0; }
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
         const double mean = s1 * a.gs_inv_count;
@@ -801,7 +805,11 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                         // issue for tens of cycles, and all four consumer waves reach the same step together -- three loads in the
                         // one-MFMA step hh = 0 (the round-1 placement, -DCCN_WLOAD_AT0=1) stalled the MFMA stream there
                         const int pg = g + DG - 1;
+#ifdef CCN_AB_WHOT
+                        const unsigned off = wb_cur;                   // timing experiment (wrong results): every group re-reads the same 3 KiB -> L1 hits
+#else
                         const unsigned off = pg < NG ? wb_cur + (unsigned)(pg * 3) * 1024u : wb_nxt + (unsigned)((pg - NG) * 3) * 1024u;
+#endif
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy) {
                             const int lh = WLOAD_AT0 ? 0 : (TH == 8 ? 2 + 2 * dy : 2 + dy);
@@ -1108,6 +1116,7 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
         if ((unsigned long long)std::max<long>(ntiles, 8192) * (unsigned long long)dmax >= 0x100000000ull) return hipErrorInvalidValue;   // CCN_FDIV exactness
         d.fd_nt = magic(a.n_nt); d.fd_ntp = magic((long)a.n_nt * a.npar); d.fd_tx = magic(a.n_tx); d.fd_sp = magic((long)a.n_tx * a.n_ty);
         d.fd_cpg = magic(a.cpg); d.fd_gscpg = magic(a.gs_cpg);
+        d.fd_gsbn = magic(a.gs_bn); d.fd_gsnsp = magic(a.gs_nsp);
     }
     // Producer waves outrank the consumers on the 2-chunk 3x3 layers (the 128-channel levels, where the producers are the pole and
     // the consumers wait a quarter of their time at barriers): +0.8 % on two boxes in product builds; on every layer: -0.5..+1.7 %

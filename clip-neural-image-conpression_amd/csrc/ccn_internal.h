@@ -71,7 +71,7 @@ struct ConvArgs {
     int th;                 // tile rows of 32 pixels per workgroup (4; 8 for the large warp-specialised tiles)
     int use_pr;             // decided at plan time: this launch runs the persistent kernel (its GroupNorm slot layout differs)
     int use_stem2;          // decided at plan time: dedicated bf16 stem kernel (ccn_stem.hip)
-    unsigned fd_nt, fd_ntp, fd_tx, fd_sp, fd_cpg, fd_gscpg;   // persistent kernel (set by launch_conv_pr): magic numbers ceil(2^32 / d) of its
+    unsigned fd_nt, fd_ntp, fd_tx, fd_sp, fd_cpg, fd_gscpg, fd_gsbn, fd_gsnsp;   // persistent kernel (set by launch_conv_pr): magic numbers ceil(2^32 / d) of its
                             // launch-constant divisors n_nt, n_nt*npar, n_tx, n_tx*n_ty, cpg, gs_cpg (0 for d == 1)
     int prod_first;         // persistent kernel (set by launch_conv_pr): producer waves at a higher priority than the consumers
     int blocked_per;        // persistent kernel (set by launch_conv_pr): > 0 = blocked tile order, tiles per workgroup

@@ -1,0 +1,432 @@
+// Micro-benchmark: the consumer wave's step of the persistent conv kernel in isolation.  One group = 8 MFMAs
+// (v_mfma_f32_32x32x16_bf16, eight accumulators = a 256-pixel x 32-channel wave tile), NDS `ds_read_b128` A fragments and
+// NLOAD 16-byte-per-lane weight loads from an L2-resident array through a three-deep register ring.  Question: what does a
+// weight load cost the wave (DESIGN finding 10 fitted ~86 cycles), and does the kind of load or the tile shape change it?
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 consumer_loop.hip -o consumer_loop && ./consumer_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned raw4;
+// MT accumulators per wave (8: 256 x 32 tile; 16: 512 x 32), NLOAD weight loads per group of MT MFMAs, NDS ds_reads per group
+template <int MT, int NLOAD, int NDS, int KIND>
+__global__ __launch_bounds__(256) void k(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters, int wstride)
+{
+    __shared__ u32x4 lds[64 * 64];                                 // 64 KB of "A fragments"
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) { u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; lds[i] = v; }
+    __syncthreads();
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+    const u32x4* wp = w + (size_t)(blockIdx.x & 3) * 4096 + wave * 1024 + lane;          // a few hundred KB in all: L2-resident
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 24, 0x00020000);
+    int voff = ((blockIdx.x & 3) * 4096 + wave * 1024 + lane) * 16;
+    u32x4 ring[3][NLOAD > 0 ? NLOAD : 1];
+    auto issue = [&](int slot, int it) __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) {
+            if (KIND == 0) ring[slot][l] = wp[((it * NLOAD + l) & 15) * 64];
+            else           ring[slot][l] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((it * NLOAD + l) & 15) * 1024, 0));
+        }
+    };
+    u32x4 bconst = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    for (int s = 0; s < 3; ++s) { if (s == 0) issue(0, 0); if (s == 1) issue(1, 1); if (s == 2) issue(2, 2); }
+    // A fragments are fetched one group ahead (two register sets), as the kernel's row-fragment prefetch does
+    u32x4 a[2][NDS > 0 ? NDS : 1];
+    a[0][0] = bconst; a[1][0] = bconst;
+    auto fetch_a = [&](int buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < NDS; ++m) a[buf][m] = lds[(g & 7) * 512 + (m & 7) * 64 + lane];
+    };
+    fetch_a(0, 0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 6) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            u32x4 b[NLOAD > 0 ? NLOAD : 1];
+            b[0] = bconst;
+            if (NLOAD > 0) {
+                // wait for this slot (two younger groups stay in flight)
+                if (NLOAD == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if (NLOAD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+                for (int l = 0; l < NLOAD; ++l) b[l] = ring[s % 3][l];
+            }
+            fetch_a((s + 1) & 1, it + s + 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int ai = NDS > 0 ? m % NDS : 0, bi = NLOAD > 1 ? m / (MT / NLOAD) : 0;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s & 1][ai]), __builtin_bit_cast(bf16x8, b[bi]), acc[m], 0, 0, 0);
+            }
+            if (NLOAD > 0) issue(s % 3, it + s + 3);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+    float r = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int MT, int NLOAD, int NDS, int KIND>
+static void run(const char* name, const u32x4* w, unsigned long long* out, float* sink, int grid)
+{
+    const int iters = 6 * 1024;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<MT, NLOAD, NDS, KIND>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters, 0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<MT, NLOAD, NDS, KIND>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters, 0);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[4]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    const double cyc = (double)h[0] / iters;                       // s_memtime ticks (100 MHz) -> use the event time for cycles
+    const double us_per_group = ms * 1e3 / iters;
+    printf("%-44s grid %3d  %.4f us/group  = %.1f cycles @2.0GHz per %d MFMAs (ideal %d)  [memtime %.3f ticks]\n", name, grid, us_per_group,
+           us_per_group * 2000.0, MT, MT * 32, cyc);
+}
+
+// The persistent kernel's real group: HR = TH + 2 halo-row fragments (ds_read_b128), 3 weight fragments (one per dy), 3 * TH MFMAs
+// (output row r takes halo rows r, r+1, r+2).  A fragments one group ahead, weights through a three-deep ring.
+template <int TH, int NDSX, int NWL>
+__global__ __launch_bounds__(256) void kg(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters)
+{
+    __shared__ u32x4 lds[64 * 64];
+    constexpr int HR = TH + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) { u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; lds[i] = v; }
+    __syncthreads();
+    f32x16 acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = (f32x16){0};
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 24, 0x00020000);
+    const int voff = ((blockIdx.x & 3) * 4096 + wave * 1024 + lane) * 16;
+    u32x4 ring[3][3];
+    u32x4 bconst = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    auto issue = [&](int slot, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (l < NWL) ring[slot][l] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((g * 3 + l) & 15) * 1024, 0));
+            else ring[slot][l] = bconst;
+        }
+    };
+    u32x4 a[2][HR];
+    auto fetch_a = [&](int buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < HR; ++m) { if (m < NDSX) a[buf][m] = lds[(g & 3) * 1024 + m * 64 + lane]; else a[buf][m] = bconst; }
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2);
+    fetch_a(0, 0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 6) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            if (NWL == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (NWL == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            fetch_a((s + 1) & 1, it + s + 1);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < TH; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s & 1][r + dy]), __builtin_bit_cast(bf16x8, ring[s % 3][dy]), acc[r], 0, 0, 0);
+            if (NWL > 0) issue(s % 3, it + s + 3);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+    float r = 0.f;
+#pragma unroll
+    for (int m = 0; m < TH; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int TH, int NDSX, int NWL>
+static void rung(const char* name, const u32x4* w, unsigned long long* out, float* sink, int grid)
+{
+    const int iters = 6 * 512;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kg<TH, NDSX, NWL>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kg<TH, NDSX, NWL>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[4]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    printf("%-44s grid %3d  %.4f us/group  [%.1f cycles per %d MFMAs, ideal %d: %.1f %%]\n", name, grid, ms * 1e3 / iters, (double)h[0] / iters, 3 * TH, 96 * TH,
+           100.0 * 96 * TH / ((double)h[0] / iters));
+}
+
+// The kernel's own step order: halo row hh feeds output rows hh, hh-1, hh-2 (dy = 0, 1, 2) -> an accumulator is reused after
+// 2-3 MFMAs; row fragments PF rows ahead through a WIN-deep window, one weight load in each of three steps of a group.
+template <int PF, int ORDER>
+__global__ __launch_bounds__(256) void kk(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters)
+{
+    __shared__ u32x4 lds[64 * 64];
+    constexpr int TH = 8, HR = 10, WIN = 6, NS = 60;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) { u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; lds[i] = v; }
+    __syncthreads();
+    f32x16 acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = (f32x16){0};
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 24, 0x00020000);
+    const int voff = ((blockIdx.x & 3) * 4096 + wave * 1024 + lane) * 16;
+    u32x4 bq[3][3], rw[WIN];
+    int sbase = 0;
+    auto rload = [&](int s_) __attribute__((always_inline)) { const int g = (s_ / HR) % 6, hh = s_ % HR; rw[s_ % WIN] = lds[(g & 3) * 1024 + hh * 64 + lane]; };
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) bq[g][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (g * 3 + dy) * 1024, 0));
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) rload(s_);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 6) {
+        sbase = (it & 8) * 1024;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int g = s_ / HR, hh = s_ % HR;
+            __builtin_amdgcn_sched_barrier(0);
+            const int pg = g + 2;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+                if (hh == 2 + 2 * dy) bq[pg % 3][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + ((pg % 6) * 3 + dy) * 1024, 0));
+            rload(s_ + PF);
+            int nm = 0;
+            if (ORDER == 0) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int i = hh - dy;
+                    if (i >= 0 && i < TH) { acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[g % 3][dy]), __builtin_bit_cast(bf16x8, rw[s_ % WIN]), acc[i], 0, 0, 0); ++nm; }
+                }
+            } else {
+#pragma unroll
+                for (int dy = 2; dy >= 0; --dy) {
+                    const int i = hh - dy;
+                    if (i >= 0 && i < TH) { acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[g % 3][dy]), __builtin_bit_cast(bf16x8, rw[s_ % WIN]), acc[i], 0, 0, 0); ++nm; }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (m == 1 && (hh == 2 || hh == 4 || hh == 6)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+    float r = 0.f;
+#pragma unroll
+    for (int m = 0; m < TH; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int PF, int ORDER>
+static void runk(const char* name, const u32x4* w, unsigned long long* out, float* sink, int grid)
+{
+    const int iters = 6 * 512;
+    hipLaunchKernelGGL((kk<PF, ORDER>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((kk<PF, ORDER>), dim3(grid), dim3(256), 0, 0, w, out, sink, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[4]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    printf("%-44s grid %3d  [%.1f cycles per 24 MFMAs, ideal 768: %.1f %%]\n", name, grid, (double)h[0] / iters, 100.0 * 768 / ((double)h[0] / iters));
+}
+
+// Co-execution: waves 0-3 run the kernel-order consumer loop (kk), waves 4-7 (one per SIMD, like the producers) issue VALU
+// work until the consumers finish: VPI VALU instructions, then a sleep of GAP*64 cycles, repeated.  How many VALU instructions
+// fit next to a group of 24 MFMAs, and what does each cost the MFMA stream?
+template <int KIND, int PRIO, int NVS = 0>
+__global__ __launch_bounds__(512) void kco(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters, int gap)
+{
+    __shared__ u32x4 lds[64 * 64];
+    __shared__ volatile int done;
+    constexpr int TH = 8, HR = 10, WIN = 6, NS = 60, PF = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 64; i += 512) { u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; lds[i] = v; }
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    if (wave >= 4) {
+        float a0 = 1.0f + lane * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+        unsigned long long n = 0;
+        while (!done) {
+            if (KIND == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            } else {
+                // the GroupNorm + SiLU mix per element: shift, fma, mul, exp, add, rcp, mul (+ half a cvt_pk)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_lshlrev_b32 %0, 16, %1\n v_fma_f32 %0, %0, %2, %3\n v_mul_f32 %1, 0xbfb8aa3b, %0\n v_exp_f32 %1, %1\n v_add_f32 %1, 1.0, %1\n v_rcp_f32 %1, %1\n v_mul_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %2, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            }
+            n += 64;
+            for (int q = 0; q < gap; ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) out[8 + wave] = n;
+        sink[threadIdx.x] = a0 + a1 + a2 + a3;
+        return;
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    f32x16 acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = (f32x16){0};
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 24, 0x00020000);
+    const int voff = ((blockIdx.x & 3) * 4096 + wave * 1024 + lane) * 16;
+    u32x4 bq[3][3], rw[WIN];
+    float ov[4] = {1.0f + lane, 2.0f, 3.0f, 4.0f};
+    int sbase = 0;
+    auto rload = [&](int s_) __attribute__((always_inline)) { const int g = (s_ / HR) % 6, hh = s_ % HR; rw[s_ % WIN] = lds[(g & 3) * 1024 + hh * 64 + lane]; };
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) bq[g][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (g * 3 + dy) * 1024, 0));
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) rload(s_);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 6) {
+        sbase = (it & 8) * 1024;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int g = s_ / HR, hh = s_ % HR;
+            __builtin_amdgcn_sched_barrier(0);
+            const int pg = g + 2;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+                if (hh == 2 + 2 * dy) bq[pg % 3][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + ((pg % 6) * 3 + dy) * 1024, 0));
+            rload(s_ + PF);
+            int nm = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int i = hh - dy;
+                if (i >= 0 && i < TH) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[g % 3][dy]), __builtin_bit_cast(bf16x8, rw[s_ % WIN]), acc[i], 0, 0, 0); ++nm;
+#pragma unroll
+                    for (int q = 0; q < NVS; ++q) { ov[q & 3] = __builtin_fmaf(ov[q & 3], ov[(q + 1) & 3], 1.0f); }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (m == 1 && (hh == 2 || hh == 4 || hh == 6)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (m < nm) __builtin_amdgcn_sched_group_barrier(0x002, NVS + 1, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) { out[wave] = t1 - t0; sink[0] = ov[0] + ov[1] + ov[2] + ov[3]; }
+    __builtin_amdgcn_s_setprio(0);
+    if (threadIdx.x == 0) done = 1;
+    float r = 0.f;
+#pragma unroll
+    for (int m = 0; m < TH; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 512 + threadIdx.x] = r;
+}
+template <int KIND, int PRIO, int NVS = 0>
+static void runco(const char* name, const u32x4* w, unsigned long long* out, float* sink, int gap)
+{
+    const int iters = 6 * 512;
+    hipMemset(out, 0, 128);
+    hipLaunchKernelGGL((kco<KIND, PRIO, NVS>), dim3(1), dim3(512), 0, 0, w, out, sink, iters, gap);
+    hipDeviceSynchronize();
+    unsigned long long h[16]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    const double cyc = (double)h[0] / iters, nv = (double)h[12] / iters;
+    printf("own %d/MFMA, %-30s sleep %2d: %.1f cycles per group (%.1f %% of MFMA rate), %.1f VALU instr per group next to it (%.2f per MFMA); extra MFMA-wave cycles per VALU instr %.2f\n",
+           NVS, name, gap, cyc, 100.0 * 768 / cyc, nv, nv / 24, nv > 0 ? (cyc - 771.0) / nv : 0.0);
+}
+
+// The consumer wave issuing VALU work itself in the shadow of its own MFMAs: NV v_fma_f32 after every MFMA (asm volatile keeps
+// program order).  No other wave on the SIMD.
+template <int NV>
+__global__ __launch_bounds__(256) void kself(unsigned long long* out, float* sink, int iters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = (f32x16){0};
+    u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+    float v0 = 1.0f + lane, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if ((q & 3) == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v0));
+                if ((q & 3) == 1) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v1));
+                if ((q & 3) == 2) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v2));
+                if ((q & 3) == 3) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v3));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+    float r = v0 + v1 + v2 + v3;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int NV>
+static void runself(unsigned long long* out, float* sink)
+{
+    const int iters = 2048;
+    hipLaunchKernelGGL((kself<NV>), dim3(1), dim3(256), 0, 0, out, sink, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[4]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    printf("own wave: %d v_fma after each MFMA: %.1f cycles per 24 MFMAs (ideal 768: %.1f %%)\n", NV, (double)h[0] / iters, 100.0 * 768 / ((double)h[0] / iters));
+}
+
+int main()
+{
+    u32x4* w; unsigned long long* out; float* sink;
+    hipMalloc(&w, 1 << 24); hipMemset(w, 0x3f, 1 << 24); hipMalloc(&out, 256); hipMalloc(&sink, 256 * 512 * 4);
+    for (int grid : {1, 256}) {
+        run<8, 0, 0, 0>("8 MFMA", w, out, sink, grid);
+        run<8, 0, 8, 0>("8 MFMA + 8 ds_read", w, out, sink, grid);
+        run<8, 1, 0, 0>("8 MFMA + 1 global_load", w, out, sink, grid);
+        run<8, 1, 0, 1>("8 MFMA + 1 buffer_load", w, out, sink, grid);
+        run<8, 1, 8, 0>("8 MFMA + 8 ds_read + 1 global_load", w, out, sink, grid);
+        run<8, 1, 8, 1>("8 MFMA + 8 ds_read + 1 buffer_load", w, out, sink, grid);
+        run<8, 2, 8, 1>("8 MFMA + 8 ds_read + 2 buffer_load", w, out, sink, grid);
+        run<16, 1, 16, 1>("16 MFMA + 16 ds_read + 1 buffer_load", w, out, sink, grid);
+        run<16, 2, 8, 1>("16 MFMA + 8 ds_read + 2 buffer_load", w, out, sink, grid);
+        run<16, 0, 16, 1>("16 MFMA + 16 ds_read", w, out, sink, grid);
+    }
+    for (int grid : {1, 256}) {
+        rung<8, 0, 0>("group 8 rows: 24 MFMA", w, out, sink, grid);
+        rung<8, 10, 0>("group 8 rows: 24 MFMA + 10 ds", w, out, sink, grid);
+        rung<8, 0, 3>("group 8 rows: 24 MFMA + 3 wload", w, out, sink, grid);
+        rung<8, 10, 3>("group 8 rows: 24 MFMA + 10 ds + 3 wload", w, out, sink, grid);
+        rung<8, 10, 1>("group 8 rows: 24 MFMA + 10 ds + 1 wload", w, out, sink, grid);
+        rung<4, 6, 3>("group 4 rows: 12 MFMA + 6 ds + 3 wload", w, out, sink, grid);
+        rung<4, 6, 0>("group 4 rows: 12 MFMA + 6 ds", w, out, sink, grid);
+    }
+    for (int grid : {1, 256}) {
+        runk<4, 0>("kernel order, PF 4", w, out, sink, grid);
+        runk<5, 0>("kernel order, PF 5", w, out, sink, grid);
+        runk<3, 0>("kernel order, PF 3", w, out, sink, grid);
+        runk<4, 1>("kernel order reversed dy, PF 4", w, out, sink, grid);
+    }
+    for (int gap : {0, 4, 8, 16, 64}) {
+        runco<1, 0, 0>("GN+SiLU mix sibling", w, out, sink, gap);
+        runco<1, 0, 1>("GN+SiLU mix sibling", w, out, sink, gap);
+        runco<1, 0, 2>("GN+SiLU mix sibling", w, out, sink, gap);
+        runco<1, 0, 3>("GN+SiLU mix sibling", w, out, sink, gap);
+        runco<1, 0, 4>("GN+SiLU mix sibling", w, out, sink, gap);
+    }
+    runself<0>(out, sink); runself<1>(out, sink); runself<2>(out, sink); runself<3>(out, sink); runself<4>(out, sink);
+    runself<5>(out, sink); runself<6>(out, sink); runself<7>(out, sink); runself<8>(out, sink);
+    return 0;
+}
