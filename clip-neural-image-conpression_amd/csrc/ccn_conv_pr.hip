@@ -687,6 +687,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_w += t1 - t0; t0 = t1;
             }
+#ifdef CCN_AB_PROD_IDLE
+            // timing experiment (wrong results): the producers only keep the barrier protocol -> the consumers' speed with nothing next to them
+            timed_barrier(); if (++c == nck) { c = 0; ++ti; } continue;
+#endif
             if (k + 1 < ktotal) { prep(); dump((k + 1) & 1); }
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
