@@ -777,6 +777,17 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         raw_barrier();                                             // chunk 0 visible
         stamp(1);
         int k = 0;
+        // Cout not a multiple of 128 (C4's 192-wide level): the last N tile is part padding.  Every tile of a workgroup has the same N
+        // tile when the grid is a multiple of n_nt (tiles are visited with stride `grid`), so a consumer wave whose 32 channels are ALL
+        // padding has nothing to compute in this launch: it only keeps the barrier protocol (the epilogue masks those channels anyway).
+#ifdef CCN_AB_NO_IDLE_PAD
+        const bool idle_w = false;
+#else
+        const bool idle_w = per == 0 && ks == 1 && grid % a.n_nt == 0 &&
+                            (vt_tile(vt(0)) - CCN_FDIV(vt_tile(vt(0)), a.fd_nt, a.n_nt) * a.n_nt) * BN + wave * 32 >= a.Cout;
+#endif
+        if (idle_w) { for (int kk = 0; kk < ktotal; ++kk) timed_barrier(); }
+        else
         for (int ti = 0; ti < my_tiles; ++ti) {
             const int v = vt(ti), v_next = ti + 1 < my_tiles ? vt(ti + 1) : v;
             const int tile = vt_tile(v), c0 = vt_kh(v) * nck;
