@@ -902,6 +902,7 @@ int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out)
     int ch = cfg->base;
     for (int i = 0; i < cfg->n_mult; ++i) {
         if (cfg->ch_mult[i] < 1) return fail(CCN_EINVAL, "ch_mult entries must be >= 1");
+        if ((long)ch * cfg->ch_mult[i] > (1 << 16)) return fail(CCN_EINVAL, "channel width (running product of ch_mult, models/unet.py:64) above 65536");
         ch *= cfg->ch_mult[i];
     }
     int ndev = 0;

@@ -25,8 +25,9 @@
 //     bias / FiLM / residual operands are fetched before the final barrier of the chunk loop;
 //   * TH = 4: the same kernel on 4-row tiles for layers with fewer than #CUs 8-row tiles.
 // Built, measured in product builds and compiled OUT (flags keep them reproducible): the last tile's epilogue split between the
-// two roles (-DCCN_AB_COOP_TAIL: +-1 % by box), write-through output stores (-DCCN_AB_SC1_STORES: -1..-2 %), blocked tile order
-// with staged input kept in LDS (-DCCN_LDS_REUSE: -3..-4 %, see CCN_REUSE below).
+// two roles (-DCCN_AB_COOP_TAIL: +-1 % by box), write-through output stores (-DCCN_AB_SC1_STORES: -1..-2 %).  Built, measured and REMOVED:
+// blocked tile order with staged input kept in LDS between neighbouring tiles (-3..-4 %: DESIGN.md section 4, finding 12; last present in
+// commit ab3fdf7).
 // Tile: TH (8 or 4) rows x 32 pixels x 128 output channels, 4 consumer waves (3x3: all rows x 32 channels each; other tap sets:
 // 2x2 waves of 4x2 fragments of 32x32) + 4 producer waves.
 // Rounding: the conv accumulator is rounded to bf16 once before the affine/residual and the sum once more on store
@@ -37,16 +38,6 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
-
-// Staged input kept in LDS between neighbouring tiles (blocked tile order; decode() in the kernel): measured in product builds on
-// one box as a NET LOSS -- 79.5 images/s without the code, 77.0 with it (its wave-uniform branches inside the producers' unrolled
-// load / stage loops cost more than the 20 % of staging it saves: with the code in place, switching the reuse on is worth +1.7 %,
-// having the code at all -5 %).  Kept behind -DCCN_LDS_REUSE for the record; the product build folds every use to false.
-#ifdef CCN_LDS_REUSE
-#define CCN_REUSE(x) (x)
-#else
-#define CCN_REUSE(x) false
-#endif
 
 namespace ccn {
 
@@ -131,16 +122,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const int grid = (int)gridDim.x;
     const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int ntiles = grid_tiles;                             // virtual tiles (x2 under split-K)
-    // Tile order of a workgroup: strided (vb, vb + grid, ...: at any moment the grid works on one contiguous band of tiles), or --
-    // a.blocked_per > 0, chosen by launch_conv_pr for 2-chunk layers -- blocked (vb*per, vb*per + 1, ...), which makes a
-    // workgroup's consecutive tiles NEIGHBOURS so that staged input can stay in LDS between them (a.reuse, see decode()).
-#ifdef CCN_AB_BLOCKED
-    const int per = a.blocked_per;                                 // A/B build: blocked tile order alone (no kept input)
-#else
-    const int per = CCN_REUSE(true) ? a.blocked_per : 0;
-#endif
-    const int my_tiles = per > 0 ? min(per, ntiles - vb * per) : (ntiles - vb + grid - 1) / grid;      // >= 1 (host: grid <= ntiles, grid = ceil(ntiles / per))
-    auto vt = [&](int ti) __attribute__((always_inline)) { return per > 0 ? vb * per + ti : vb + ti * grid; };
+    // Tile order of a workgroup: strided (vb, vb + grid, ...): at any moment the grid works on one contiguous band of tiles
+    const int my_tiles = (ntiles - vb + grid - 1) / grid;          // >= 1 (host: grid <= ntiles)
+    auto vt = [&](int ti) __attribute__((always_inline)) { return vb + ti * grid; };
     // split-K launches run the MODE 2 instantiation only (launch_conv_pr): everywhere else ks folds to 1 at compile time and the
     // hand-off branches of the epilogue disappear
 #ifdef CCN_AB_RUNTIME_KS
@@ -185,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
     };
     // diagnostics (CCN_STAMPS): shader-clock cycles spent waiting at barriers / in phases, per role
-    unsigned long long t_bar = 0, t_a = 0, t_b = 0, t_w = 0, t_r = 0;
+    [[maybe_unused]] unsigned long long t_bar = 0, t_a = 0, t_b = 0, t_w = 0, t_r = 0;
     const unsigned long long t_begin = CCN_STAMPS_PTR(a) ? __builtin_amdgcn_s_memtime() : 0;
     auto timed_barrier = [&]() __attribute__((always_inline)) {
         if (CCN_STAMPS_PTR(a)) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); raw_barrier(); t_bar += __builtin_amdgcn_s_memtime() - t0; }
@@ -235,17 +219,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         e_nt = tile - t2 * a.n_nt;
         e_par = t2 % NPARC;
         const int sp = t2 / NPARC;
-#ifdef CCN_LDS_REUSE
-        e_tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx; e_ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
-        e_b = sp / (a.n_tx * a.n_ty);
-#else
         {
             const int row = CCN_FDIV(sp, a.fd_tx, a.n_tx);                    // (b, ty) row of tiles
             e_tx = sp - row * a.n_tx;
             e_b = CCN_FDIV(sp, a.fd_sp, a.n_tx * a.n_ty);
             e_ty = row - e_b * a.n_ty;
         }
-#endif
         const int nb = e_nt * BN + o16 * 8;
         const bool nvalid = nb < a.Cout;
         // output pixel of M-space pixel (my, mx): (my*OS + py, mx*OS + px) -- OS = 2 and 4 parities for the ConvTranspose
@@ -454,7 +433,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     u32x4 areg[AIT];
     GnCoef<T> gk;
     unsigned rowm = 0;                       // wave-uniform: bit i = halo row i inside the image (for the chunk in areg)
-    bool colv = false, xv = false, x_vr = false;   // this thread's column / extra item inside the image; extra item reused
+    bool colv = false, xv = false;           // this thread's column / extra item inside the image
     int rq_ti = 0, rq_c = 0;
     // A request is split in two: prep() at the START of an iteration decodes the tile and fetches the GroupNorm
     // coefficients of the chunk into a second register set; issue() after dump() sends the 11 input loads and adopts the
@@ -507,30 +486,17 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // prep() = decode (tile / chunk of the next request) + coefficients; split so that the FIRST request of the kernel can put
     // its input loads in front of the statistics' round trip (request_first below)
     int q_cbs = 0; bool q_cv = false, q_cv_i = false;
-    bool q_skip = false, q_vr = false, d_skip = false, d_vr = false;      // wave-uniform; d_*: of the chunk whose loads are in areg
     auto decode = [&]() __attribute__((always_inline)) -> bool {
         const int v = vt(rq_ti);
         if (rq_c == 0) {                                       // new tile: decode it once, not once per chunk (the divisions are ~100 SALU ops)
             q_tv = rq_ti < my_tiles;
             const int tile = vt_tile(q_tv ? v : vt(0));
             const int sp = CCN_FDIV(tile, a.fd_ntp, a.n_nt * NPARC);   // tile = ((spatial tile) * npar + parity) * n_nt + N tile
-#ifdef CCN_LDS_REUSE
-            // a.reuse == 2 walks a sample's tiles column by column (ty fastest) so that consecutive tiles are vertical neighbours
-            const int tx = CCN_REUSE(a.reuse == 2) ? (sp / a.n_ty) % a.n_tx : sp % a.n_tx, ty = CCN_REUSE(a.reuse == 2) ? sp % a.n_ty : (sp / a.n_tx) % a.n_ty;
-            q_b = sp / (a.n_tx * a.n_ty);
-#else
             const int row = CCN_FDIV(sp, a.fd_tx, a.n_tx);
             const int tx = sp - row * a.n_tx;
             q_b = CCN_FDIV(sp, a.fd_sp, a.n_tx * a.n_ty);
             const int ty = row - q_b * a.n_ty;
-#endif
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
-            // Input already in LDS (2-chunk layers: chunk c of every tile lives in buffer c; blocked order; not the workgroup's
-            // first tile): reuse 1 (ConvTranspose) -- parities 1..3 of a spatial tile read exactly the input parity 0 staged:
-            // nothing to load or stage; reuse 2 (3x3 s1) -- the tile below the previous one: its halo rows 0, 1 are the
-            // previous tile's rows 8, 9, copied inside LDS instead of loaded and transformed again
-            q_skip = CCN_REUSE(a.reuse == 1 && q_tv && rq_ti > 0 && (tile / a.n_nt) % NPARC != 0);
-            q_vr = CCN_REUSE(TH == 8 && a.reuse == 2 && q_tv && rq_ti > 0 && ty > 0);
         }
         q_c = vt_kh(v) * nck + rq_c;
         const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
@@ -572,8 +538,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int cb = cc * CKE + ck * EPC;
         const bool cv = q_tv && cb < a.Cin;
         q_cv_i = cv;
-        d_skip = q_skip; d_vr = q_vr;
-        if (CCN_REUSE(d_skip)) return;                                        // the chunk is in LDS already
         // The descriptor is WAVE-UNIFORM (a lane-dependent base makes the compiler wrap every load in a readfirstlane waterfall
         // loop) and covers exactly sample b from this chunk's channels on: halo rows above the image give negative = huge
         // unsigned offsets, rows below it run past num_records, so the hardware range check zero-fills both with no
@@ -594,15 +558,13 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
         for (int i = 0; i < HROWS; ++i) {
             if (i < r0 || i >= r1) continue;
-            if (i < 2 && CCN_REUSE(d_vr)) continue;                           // rows 0, 1 come from the previous tile's rows 8, 9
             areg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)(base + i * rs) | cmask, 0, 0);
         }
         {
             const int iyr = IS * (iy0 + xrow) + py, ixx = IS * (ix0 + xcol) + px;
             xv = xthr && cv && iyr >= 0 && iyr < a.Hin && ixx >= 0 && ixx < a.Win;
-            x_vr = CCN_REUSE(d_vr && xrow < 2);                               // (columns 32, 33 of the reused rows)
             const int off = (iyr * a.Win + ixx) * a.Cin * (int)sizeof(T) + ck * 16;
-            if (with_x) areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | ((xv && !CCN_REUSE(x_vr)) ? 0u : OOB), 0, 0);
+            if (with_x) areg[HROWS] = __builtin_amdgcn_raw_buffer_load_b128(srd, (unsigned)off | (xv ? 0u : OOB), 0, 0);
         }
     };
     auto issue = [&]() __attribute__((always_inline)) { issue_loads(); adopt(); };
@@ -619,7 +581,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         adopt();
     };
     auto dump = [&](int buf, int r0 = 0, int r1 = TH + 2, bool with_x = true) __attribute__((always_inline)) {
-        if (CCN_REUSE(d_skip)) return;
         unsigned char* const As = smem + buf * L::A_BYTES;
         int pc = pcol; asm volatile("" : "+v"(pc));               // LDS addresses recomputed here, not kept live across the loop
         // LDS rows of 128 B, 16-byte slices XOR-swizzled by the halo COLUMN ((hx >> 1) & 7): a tap's dy then moves a
@@ -630,20 +591,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
             const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
             u32x4 v = areg[i];
-            if constexpr (TH == 8) {
-                // vertical reuse: the finished (transformed) rows 8, 9 of the previous tile's same chunk sit in this buffer; this
-                // thread's reads of them precede its own writes of the new rows 8, 9 below (program order, LDS in order per wave)
-                if (i < 2 && CCN_REUSE(d_vr)) {
-                    *(u32x4*)(As + px * 128 + (((ck ^ sw) & 7) << 4)) = *(const u32x4*)(As + (px + 8 * HPITCH) * 128 + (((ck ^ sw) & 7) << 4));
-                    continue;
-                }
-                if (i == HROWS && CCN_REUSE(d_vr)) {
-                    // columns 32, 33: the copy is done by the thread that OWNS the source (halo rows 8, 9), right before it
-                    // overwrites it with the new tile's value -- a copy by the owner of rows 0, 1 would race with that write
-                    if (xthr && (pc >> 1) >= 8) *(u32x4*)(As + (px - 8 * HPITCH) * 128 + ((ck & 7) << 4)) = *(const u32x4*)(As + px * 128 + ((ck & 7) << 4));
-                    if (CCN_REUSE(x_vr)) continue;
-                }
-            }
             const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
             if (gn) {
                 const u32x4 tr = gk.template apply<true>(v);
@@ -783,7 +730,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #ifdef CCN_AB_NO_IDLE_PAD
         const bool idle_w = false;
 #else
-        const bool idle_w = per == 0 && ks == 1 && grid % a.n_nt == 0 &&
+        const bool idle_w = ks == 1 && grid % a.n_nt == 0 &&
                             (vt_tile(vt(0)) - CCN_FDIV(vt_tile(vt(0)), a.fd_nt, a.n_nt) * a.n_nt) * BN + wave * 32 >= a.Cout;
 #endif
         if (idle_w) { for (int kk = 0; kk < ktotal; ++kk) timed_barrier(); }
@@ -1121,10 +1068,6 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // every round of the persistent loop.  Fewer than 16 virtual tiles: the layer is too small for this kernel anyway.
     if (ks == 2) { grid &= ~15; if (grid < 16) return hipErrorInvalidValue; }
     ConvArgs d = a;
-    // 2-chunk layers with one N tile (the 128-channel levels of C2): blocked tile order + input kept in LDS between neighbouring
-    // tiles.  ConvTranspose: the four parities of a spatial tile (consecutive tile ids) share their staged input; 3x3 s1: a tile
-    // reuses the two bottom halo rows of the tile above it.
-    d.blocked_per = 0; d.reuse = 0;
     {
         auto magic = [](long dv) -> unsigned { return dv <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)dv - 1) / (unsigned long long)dv); };
         const long dmax = std::max<long>(std::max<long>((long)a.n_nt * a.npar, (long)a.n_tx * a.n_ty), std::max<long>(a.cpg, a.gs_cpg));
@@ -1141,18 +1084,6 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
 #else
     d.prod_first = (a.nchunk <= 2 && c3) ? 1 : 0;
 #endif
-#if defined(CCN_LDS_REUSE) || defined(CCN_AB_BLOCKED)
-    static const bool no_reuse = diag_env("CCN_NO_REUSE") != nullptr;
-#else
-    static const bool no_reuse = true;                                        // product build: see CCN_REUSE at the top of this file
-#endif
-    if (!no_reuse && ks == 1 && a.n_nt == 1 && a.nchunk == 2 && ntiles > grid && (ct || (c3 && a.th == 8 && a.n_ty > 1))) {
-        const int per = (ntiles + grid - 1) / grid;
-        if (!ct || (per & 3) == 0) {
-            d.blocked_per = per; d.reuse = ct ? 1 : 2;
-            grid = (ntiles + per - 1) / per;
-        }
-    }
     static const char* env = diag_env("CCN_STAMPS");
     if (env && (unsigned)atoi(env) == (unsigned)ntiles && (!strchr(env, ':') || atoi(strchr(env, ':') + 1) == a.ntaps)) {   // CCN_STAMPS=<tiles>[:<ntaps>]
         if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }

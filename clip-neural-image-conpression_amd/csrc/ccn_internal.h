@@ -74,8 +74,6 @@ struct ConvArgs {
     unsigned fd_nt, fd_ntp, fd_tx, fd_sp, fd_cpg, fd_gscpg, fd_gsbn, fd_gsnsp;   // persistent kernel (set by launch_conv_pr): magic numbers ceil(2^32 / d) of its
                             // launch-constant divisors n_nt, n_nt*npar, n_tx, n_tx*n_ty, cpg, gs_cpg (0 for d == 1)
     int prod_first;         // persistent kernel (set by launch_conv_pr): producer waves at a higher priority than the consumers
-    int blocked_per;        // persistent kernel (set by launch_conv_pr): > 0 = blocked tile order, tiles per workgroup
-    int reuse;              // ... with staged input kept in LDS between consecutive tiles: 1 ConvTranspose parities, 2 vertical neighbours (3x3 s1)
     int ksplit;             // persistent kernel: 2 = split the Cin chunks over two workgroups per tile (small layers), else 1
     void* kpart;            // split-K: bf16 partial tensor, laid out like `out`
     unsigned* kflag;        // split-K: [tiles][4] hand-off flags, zero between launches
