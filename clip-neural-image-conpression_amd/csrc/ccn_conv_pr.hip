@@ -719,7 +719,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int stg_lane = r * L::SP + (wave * 32 + 4 * h) * 2;
         if constexpr (HSPLIT < HROWS) {
             request_first(HSPLIT, HROWS, false);                   // the consumers' share of the first chunk (they are idle until it is staged)
+            if (CCN_STAMPS_PTR(a)) {                               // diagnostics: the cold start in three parts [100 MHz ticks since this wave's start]
+                const unsigned long long r0 = CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 2) * 8];
+                t_a = __builtin_amdgcn_s_memrealtime() - r0;       // statistics reduced, coefficients ready, input loads issued
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t_b = __builtin_amdgcn_s_memrealtime() - r0;       // input (and first weights) arrived
+            }
             dump(0, HSPLIT, HROWS, false);
+            if (CCN_STAMPS_PTR(a)) t_r = __builtin_amdgcn_s_memrealtime() - CCN_STAMPS_PTR(a)[((size_t)blockIdx.x * 2) * 8];   // staged
         }
         raw_barrier();                                             // chunk 0 visible
         stamp(1);

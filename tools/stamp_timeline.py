@@ -16,5 +16,7 @@ print(f"consumer: chunk0 visible at {us(c[:,1]).mean():.2f} (from own start {((c
 print(f"producer: exits at {us(p[:,2]).mean():.2f} (max {us(p[:,2]).max():.2f}); tail after consumers {((p[:,2]-c[:,2])/100).mean():.2f} us; "
       f"barrier wait {(p[:,3]/p[:,4]*(p[:,2]-p[:,0])/100).mean():.2f} us, dump {(p[:,5]/p[:,4]*(p[:,2]-p[:,0])/100).mean():.2f}, "
       f"epilogue {(p[:,6]/p[:,4]*(p[:,2]-p[:,0])/100).mean():.2f}, request {(p[:,7]/p[:,4]*(p[:,2]-p[:,0])/100).mean():.2f} us")
+print(f"consumer cold start (own clock, us since its start): request done {(c[:,5]/100).mean():.2f}, loads arrived {(c[:,6]/100).mean():.2f}, own rows staged {(c[:,7]/100).mean():.2f}, "
+      f"chunk 0 visible {((c[:,1]-c[:,0])/100).mean():.2f}")
 clk = p[:, 4] / np.maximum((p[:, 2] - p[:, 0]) / 100.0, 1e-9) / 1e3
 print(f"kernel span (first start -> last exit) {us(p[:,2]).max():.2f} us; shader clock {clk.mean():.2f} GHz")
