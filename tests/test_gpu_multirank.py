@@ -68,12 +68,13 @@ def _run_eval(store, ckpt, out_json, gpus, batch, dtype, size, steps):
     return json.loads(Path(out_json).read_text())
 
 
-@pytest.mark.parametrize("n,batch,dtype,base,ch_mult", [
-    (16, 8, "bf16", 128, (1, 2, 2)),        # C3's shape in small: C2 architecture, one full batch of 8 per rank, throughput mode
-    (11, 4, "fp32", 32, (1, 2)),            # ragged: rank 0 gets 6 records (4 + 2), rank 1 gets 5 (4 + 1); single process 4 + 4 + 3
+@pytest.mark.parametrize("n,batch,dtype,base,ch_mult,world", [
+    (16, 8, "bf16", 128, (1, 2, 2), 2),     # C3's shape in small: C2 architecture, one full batch of 8 per rank, throughput mode
+    (11, 4, "fp32", 32, (1, 2), 2),         # ragged: rank 0 gets 6 records (4 + 2), rank 1 gets 5 (4 + 1); single process 4 + 4 + 3
+    (13, 2, "fp32", 32, (1, 2), 4),         # four ranks on the card, ragged: 4 / 3 / 3 / 3 records in batches of 2 (2+2, 2+1, 2+1, 2+1)
 ])
-def test_cli_eval_two_ranks_equal_single_process(tmp_path, n, batch, dtype, base, ch_mult):
-    """cli.eval (reference loop: cli/eval.py:56-86) with the real fused sampler on two fresh ranks sharding the store r::2, one
+def test_cli_eval_ranks_equal_single_process(tmp_path, n, batch, dtype, base, ch_mult, world):
+    """cli.eval (reference loop: cli/eval.py:56-86) with the real fused sampler on `world` fresh ranks sharding the store r::world, one
     all-gather at the end, against the single-process run of the same command: same records in manifest order, every metric equal.
     Records are independent units and start noise is seeded per record, so sharding must not change any row.  Rows are bit-equal when a
     record sits in a batch of the same size in both runs; in the ragged case the tail batches differ in size (3 vs 2 and 1), which can
@@ -86,9 +87,9 @@ def test_cli_eval_two_ranks_equal_single_process(tmp_path, n, batch, dtype, base
     ckpt = tmp_path / "ckpt.pt"
     torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
     one = _run_eval(store, ckpt, tmp_path / "one.json", None, batch, dtype, size, steps)
-    two = _run_eval(store, ckpt, tmp_path / "two.json", 2, batch, dtype, size, steps)
+    two = _run_eval(store, ckpt, tmp_path / "two.json", world, batch, dtype, size, steps)
     assert len(one) == len(two) == n and [r["image"] for r in one] == [r["image"] for r in two]
-    same_batch_size = n % (2 * batch) == 0
+    same_batch_size = n % (world * batch) == 0
     for i, (a, b) in enumerate(zip(one, two)):
         assert np.isfinite(a["psnr"]) and np.isfinite(a["ssim"])
         for k in ("psnr", "ssim"):
