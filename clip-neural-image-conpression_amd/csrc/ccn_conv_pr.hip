@@ -770,9 +770,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     __builtin_amdgcn_sched_barrier(0);
                     {
                         // refill the ring slot group g-1 released with the fragments of group g+DG-1 (wraps into the next chunk / tile).
-                        // One 1-KiB load per step, in the steps that carry three MFMAs: a wave-wide 16-byte load holds the wave's
-                        // issue for tens of cycles, and all four consumer waves reach the same step together -- three loads in the
-                        // one-MFMA step hh = 0 (the round-1 placement, -DCCN_WLOAD_AT0=1) stalled the MFMA stream there
+                        // One 1-KiB load per step, in the steps that carry three MFMAs (all four consumer waves reach the same step
+                        // together; three loads in the one-MFMA step hh = 0 was the round-1 placement, -DCCN_WLOAD_AT0=1).  Alone this
+                        // loop runs at 99.6 % of the MFMA rate (tools/ubench/consumer_loop.hip); next to the producers the loads
+                        // share the CU's vector-memory pipe with their traffic (finding 10).
                         const int pg = g + DG - 1;
 #ifdef CCN_AB_WHOT
                         const unsigned off = wb_cur;                   // timing experiment (wrong results): every group re-reads the same 3 KiB -> L1 hits
