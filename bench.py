@@ -180,6 +180,11 @@ def main() -> None:
             "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
             "algorithmic_gflop_per_launch": round(dom["flops"] / dom["calls"] / 1e9, 3),
             "kernel_hbm_gbs_algorithmic": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+            # informational, STORED from tools/power_probe_ubench.sh (finding 13): the dense bf16 rate the chip sustains on
+            # random operands -- 1.77 GHz register-resident, 1.55-1.57 GHz with this kernel's LDS / L2 operand traffic at 99.6 % MFMA issue
+            "sustained_peak_random_operands": ({"tflops": 1630.0, "frac": round(tfs / 1630.0, 4),
+                                                "source": "stored: tools/ubench/consumer_loop.hip loop_rnd on all CUs, 1.55-1.57 GHz (not this run)"}
+                                               if args.dtype == "bf16" else None),
             "families_ms": {f["name"]: round(f["ms"], 3) for f in fams},
             "event_pass_ms": round(total_ms, 2),
             "whole_forward": {"gflop_per_image": round(flops_fwd / B / 1e9, 2), "mb_per_image": round(bytes_fwd / B / 1e6, 1),

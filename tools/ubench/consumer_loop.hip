@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -166,12 +168,24 @@ static void rung(const char* name, const u32x4* w, unsigned long long* out, floa
 // The kernel's own step order: halo row hh feeds output rows hh, hh-1, hh-2 (dy = 0, 1, 2) -> an accumulator is reused after
 // 2-3 MFMAs; row fragments PF rows ahead through a WIN-deep window, one weight load in each of three steps of a group.
 template <int PF, int ORDER>
-__global__ __launch_bounds__(256) void kk(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters)
+__global__ __launch_bounds__(256) void kk(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters, int rnd = 0)
 {
     __shared__ u32x4 lds[64 * 64];
     constexpr int TH = 8, HR = 10, WIN = 6, NS = 60;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) { u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; lds[i] = v; }
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        u32x4 v = {0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        if (rnd) {                                               // random bf16 pairs of magnitude ~0.25..2 (operand toggling like real activations)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h = (unsigned)(i * 4 + q) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                const unsigned lo = ((h & 1u) << 15) | ((125u + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 0x7fu);
+                const unsigned hi = (((h >> 10) & 1u) << 15) | ((125u + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 0x7fu);
+                v[q] = lo | (hi << 16);
+            }
+        }
+        lds[i] = v;
+    }
     __syncthreads();
     f32x16 acc[TH];
 #pragma unroll
@@ -349,13 +363,22 @@ static void runco(const char* name, const u32x4* w, unsigned long long* out, flo
 // The consumer wave issuing VALU work itself in the shadow of its own MFMAs: NV v_fma_f32 after every MFMA (asm volatile keeps
 // program order).  No other wave on the SIMD.
 template <int NV>
-__global__ __launch_bounds__(256) void kself(unsigned long long* out, float* sink, int iters)
+__global__ __launch_bounds__(256) void kself(unsigned long long* out, float* sink, int iters, int rnd = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x16 acc[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = (f32x16){0};
     u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+    if (rnd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h = (unsigned)(threadIdx.x * 8 + q) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            a[q] = ((h & 1u) << 15) | ((125u + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 0x7fu) | ((((h >> 10) & 1u) << 15 | ((125u + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 0x7fu)) << 16);
+            h = h * 1664525u + 1013904223u;
+            b[q] = ((h & 1u) << 15) | ((122u + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 0x7fu) | ((((h >> 10) & 1u) << 15 | ((122u + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 0x7fu)) << 16);
+        }
+    }
     float v0 = 1.0f + lane, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -388,8 +411,51 @@ static void runself(unsigned long long* out, float* sink)
     printf("own wave: %d v_fma after each MFMA: %.1f cycles per 24 MFMAs (ideal 768: %.1f %%)\n", NV, (double)h[0] / iters, 100.0 * 768 / ((double)h[0] / iters));
 }
 
-int main()
+// power mode: `consumer_loop <variant> [seconds]` keeps one variant running on all CUs (tools/power_probe_ubench.sh samples rocm-smi beside it)
+template <typename F> static void spin(F launch, double seconds)
 {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    double total = 0; long n = 0;
+    while (total < seconds * 1e3) {
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) launch();
+        (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); total += ms; n += 20;
+    }
+    printf("ran %ld launches in %.1f ms (%.3f ms each)\n", n, total, total / n);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1) {
+        u32x4* w; unsigned long long* out; float* sink;
+        (void)hipMalloc(&w, 1 << 24); (void)hipMemset(w, 0x3f, 1 << 24); (void)hipMalloc(&out, 256); (void)hipMalloc(&sink, 256 * 512 * 4);
+        const double sec = argc > 2 ? atof(argv[2]) : 4.0;
+        const int iters = 6 * 2048;
+        const std::string v = argv[1];
+        if (v == "mfma") spin([&] { hipLaunchKernelGGL((kself<0>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3, 0); }, sec);
+        else if (v == "mfma_rnd") spin([&] { hipLaunchKernelGGL((kself<0>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3, 1); }, sec);
+        else if (v == "mfma_valu4") spin([&] { hipLaunchKernelGGL((kself<4>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3); }, sec);
+        else if (v == "loop") spin([&] { hipLaunchKernelGGL((kk<4, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 0); }, sec);
+        else if (v == "loop_rnd") {
+            std::vector<unsigned> hw((1 << 24) / 4);
+            unsigned st = 12345u;
+            for (auto& x : hw) {
+                st = st * 1664525u + 1013904223u; const unsigned h = st ^ (st >> 13);
+                const unsigned lo = ((h & 1u) << 15) | ((122u + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 0x7fu);
+                const unsigned hi = (((h >> 10) & 1u) << 15) | ((122u + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 0x7fu);
+                x = lo | (hi << 16);
+            }
+            (void)hipMemcpy(w, hw.data(), 1 << 24, hipMemcpyHostToDevice);
+            spin([&] { hipLaunchKernelGGL((kk<4, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1); }, sec);
+        }
+        else if (v == "loop_lds_only") spin([&] { hipLaunchKernelGGL((kg<8, 10, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters); }, sec);
+        else if (v == "loop_w_only") spin([&] { hipLaunchKernelGGL((kg<8, 0, 3>), dim3(256), dim3(256), 0, 0, w, out, sink, iters); }, sec);
+        else if (v == "loop_sibling") spin([&] { hipLaunchKernelGGL((kco<1, 0, 0>), dim3(256), dim3(512), 0, 0, w, out, sink, iters, 0); }, sec);
+        else { printf("unknown variant\n"); return 1; }
+        return 0;
+    }
+    {
     u32x4* w; unsigned long long* out; float* sink;
     hipMalloc(&w, 1 << 24); hipMemset(w, 0x3f, 1 << 24); hipMalloc(&out, 256); hipMalloc(&sink, 256 * 512 * 4);
     for (int grid : {1, 256}) {
@@ -429,4 +495,5 @@ int main()
     runself<0>(out, sink); runself<1>(out, sink); runself<2>(out, sink); runself<3>(out, sink); runself<4>(out, sink);
     runself<5>(out, sink); runself<6>(out, sink); runself<7>(out, sink); runself<8>(out, sink);
     return 0;
+    }
 }
