@@ -425,16 +425,63 @@ template <typename F> static void spin(F launch, double seconds)
     printf("ran %ld launches in %.1f ms (%.3f ms each)\n", n, total, total / n);
 }
 
+// Symmetric alternative to warp specialisation: WPS waves per SIMD, EVERY wave issues MFMAs and NV independent VALU instructions after each
+// of them (its share of staging / epilogue work in the shadow of its own MFMAs).  Reports cycles per MFMA issued on a SIMD.
+template <int NV, int WPS>
+__global__ __launch_bounds__(256 * WPS) void ksym(unsigned long long* out, float* sink, int iters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = (f32x16){0};
+    u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+    float v0 = 1.0f + lane, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if ((q & 3) == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v0));
+                if ((q & 3) == 1) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v1));
+                if ((q & 3) == 2) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v2));
+                if ((q & 3) == 3) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v3));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;          // (t0 was taken behind a workgroup barrier: common start)
+    float r = v0 + v1 + v2 + v3;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) r += acc[m][0] + acc[m][7];
+    sink[blockIdx.x * 256 * WPS + threadIdx.x] = r;
+}
+template <int NV, int WPS>
+static void runsym(unsigned long long* out, float* sink)
+{
+    const int iters = 1024;
+    hipLaunchKernelGGL((ksym<NV, WPS>), dim3(1), dim3(256 * WPS), 0, 0, out, sink, iters);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[8]; (void)hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    unsigned long long mx = 0; for (int i = 0; i < 4 * WPS; ++i) mx = h[i] > mx ? h[i] : mx;    // the SIMD's last wave (the older wave wins the MFMA issue)
+    const double cyc = (double)mx / (iters * 24.0) / WPS;          // cycles per MFMA issued on one SIMD
+    printf("symmetric: %d wave(s) per SIMD, %d v_fma after each MFMA: %.1f cycles per MFMA on the SIMD (%.1f %% of the MFMA rate), %d VALU per MFMA\n", WPS, NV, cyc, 3200.0 / cyc, NV);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) {
         u32x4* w; unsigned long long* out; float* sink;
-        (void)hipMalloc(&w, 1 << 24); (void)hipMemset(w, 0x3f, 1 << 24); (void)hipMalloc(&out, 256); (void)hipMalloc(&sink, 256 * 512 * 4);
+        (void)hipMalloc(&w, 1 << 24); (void)hipMemset(w, 0x3f, 1 << 24); (void)hipMalloc(&out, 256); (void)hipMalloc(&sink, 256 * 1024 * 4);
         const double sec = argc > 2 ? atof(argv[2]) : 4.0;
         const int iters = 6 * 2048;
         const std::string v = argv[1];
         if (v == "mfma") spin([&] { hipLaunchKernelGGL((kself<0>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3, 0); }, sec);
         else if (v == "mfma_rnd") spin([&] { hipLaunchKernelGGL((kself<0>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3, 1); }, sec);
+        else if (v == "sym2") spin([&] { hipLaunchKernelGGL((ksym<0, 2>), dim3(256), dim3(512), 0, 0, out, sink, iters / 3); }, sec);
+        else if (v == "sym1") spin([&] { hipLaunchKernelGGL((ksym<0, 1>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3); }, sec);
         else if (v == "mfma_valu4") spin([&] { hipLaunchKernelGGL((kself<4>), dim3(256), dim3(256), 0, 0, out, sink, iters / 3); }, sec);
         else if (v == "loop") spin([&] { hipLaunchKernelGGL((kk<4, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 0); }, sec);
         else if (v == "loop_rnd") {
@@ -457,7 +504,7 @@ int main(int argc, char** argv)
     }
     {
     u32x4* w; unsigned long long* out; float* sink;
-    hipMalloc(&w, 1 << 24); hipMemset(w, 0x3f, 1 << 24); hipMalloc(&out, 256); hipMalloc(&sink, 256 * 512 * 4);
+    hipMalloc(&w, 1 << 24); hipMemset(w, 0x3f, 1 << 24); hipMalloc(&out, 256); hipMalloc(&sink, 256 * 1024 * 4);
     for (int grid : {1, 256}) {
         run<8, 0, 0, 0>("8 MFMA", w, out, sink, grid);
         run<8, 0, 8, 0>("8 MFMA + 8 ds_read", w, out, sink, grid);
@@ -492,6 +539,7 @@ int main(int argc, char** argv)
         runco<1, 0, 3>("GN+SiLU mix sibling", w, out, sink, gap);
         runco<1, 0, 4>("GN+SiLU mix sibling", w, out, sink, gap);
     }
+    runsym<0, 2>(out, sink); runsym<2, 2>(out, sink); runsym<3, 2>(out, sink); runsym<4, 2>(out, sink); runsym<5, 2>(out, sink); runsym<6, 2>(out, sink); runsym<7, 2>(out, sink); runsym<8, 2>(out, sink);
     runself<0>(out, sink); runself<1>(out, sink); runself<2>(out, sink); runself<3>(out, sink); runself<4>(out, sink);
     runself<5>(out, sink); runself<6>(out, sink); runself<7>(out, sink); runself<8>(out, sink);
     return 0;
