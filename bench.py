@@ -52,11 +52,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="most DDIM steps of the CPU-baseline sample (batch 1)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise torch.distributed (RCCL) even at --gpus 1: barrier / all-gather / all-reduce of the N > 1 route run on one GPU")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (bf16 vs the reference's golden / fp32 mode, PSNR delta)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: start the N ranks ourselves (child processes, before this process touches the GPU)
-    from clip_feature_codec.utils.launch import ensure_ranks, init_process_group, rank_env, collective_device
+    from clip_feature_codec.utils.launch import ensure_ranks, init_process_group, rank_env, collective_device, single_rank_env
     ensure_ranks(args.gpus, str(Path(__file__).resolve()))
 
     import torch.distributed as dist
@@ -73,7 +75,10 @@ def main() -> None:
     dev = f"cuda:{local % torch.cuda.device_count()}"
     torch.cuda.set_device(dev)
     ranks_seen = 1
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
+        if world == 1:
+            single_rank_env()
         # RCCL ("nccl") on a GPU node; CCN_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on one card
         init_process_group(dev)
         ones = torch.ones(1, device=dev)
@@ -112,7 +117,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,7 +132,7 @@ def main() -> None:
     x = outs[-1]
     dt = time.perf_counter() - t0
     per_rank = [B * args.steps / dt_own]
-    if world > 1:
+    if use_pg:
         mine = torch.tensor([dt, dt_own], dtype=torch.float64, device=collective_device(dev))
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -142,7 +147,7 @@ def main() -> None:
         keep = [step(i, lanes) for i in range(n)]
         fence()
         d = time.perf_counter() - t1
-        if world > 1:
+        if use_pg:
             tt = torch.tensor([d], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
@@ -299,12 +304,12 @@ def main() -> None:
                        "graph": "hipGraph, one replay per step",
                        "steps_in_flight": nfl,
                        ("value_with_two_steps_in_flight" if nfl == 1 else "value_with_one_step_in_flight"): other_value},
-            "rccl_ranks": ranks_seen, "backend": (dist.get_backend() if world > 1 else None),
+            "rccl_ranks": ranks_seen, "backend": (dist.get_backend() if use_pg else None),
             "per_rank_images_per_sec": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)},
             "roofline": roofline, "parity": parity, "parity_mode": parity_mode, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ccn_load_param": (c_i32, [c_vp, ctypes.c_char_p, c_vp, ctypes.POINTER(c_i64), c_i32]),
     "ccn_commit_params": (c_i32, [c_vp]),
     "ccn_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
+    "ccn_release_workspace": (c_i32, [c_vp, c_vp]),
     "ccn_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "ccn_sample": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp, c_i32]),
     "ccn_sample_eta": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_i32]),
@@ -204,13 +205,18 @@ class NativeUNet:
             # as many live workspaces as the library caches plans (8): the least recently used one goes back to torch's
             # allocator, after draining the device -- a replay on a side stream may still be writing it
             while len(self._ws) >= self.MAX_WORKSPACES:
-                torch.cuda.synchronize(self.device)
-                self._ws.pop(next(iter(self._ws)))
+                self._release(self._ws.pop(next(iter(self._ws))))
             n = c_sz()
             check(self.lib.ccn_workspace_bytes(self.h, B, H, W, steps, ctypes.byref(n)))
             ws = Workspace(n.value, self.device)
         self._ws[key] = ws                        # (re)insert as most recently used
         return ws
+
+    def _release(self, ws: "Workspace") -> None:
+        """Before a workspace goes back to torch's allocator: the library drains the device and drops every plan / captured graph
+        that lives in it (a later workspace of the same shape may land on the same address and must not find the stale plan)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.ccn_release_workspace(self.h, ws.ptr))
 
     # -- hot path ----------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, z: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -51,7 +51,7 @@ def gather_metric_rows(local_idx: Sequence[int], local_rows: np.ndarray, n_total
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     out = np.full((n_total, len(METRIC_KEYS)), np.nan, dtype=np.float64)
-    if world == 1:
+    if not dist.is_initialized():                                  # (a one-rank GROUP still goes through the collective below)
         for i, row in zip(local_idx, local_rows):
             out[i] = row
         return out
@@ -175,12 +175,15 @@ def main(argv=None) -> None:
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--timing", action="store_true", help="print set-up and loop wall time (records/s of the loop) to stderr")
     ap.add_argument("--workers", type=int, default=None, help="host threads for decode / metrics (default: this rank's share of the CPUs, 2..16)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise torch.distributed even for one rank, so that the final all-gather runs through the backend "
+                         "(RCCL on a one-GPU box)")
     ap.add_argument("--gpus", type=int, default=None,
                     help="shard the store over this many GPUs of the node: one process per GPU is started here unless a launcher "
                          "(torchrun) already did; default: the launcher's WORLD_SIZE, else 1")
     args = ap.parse_args(argv)
 
-    from ..utils.launch import ensure_ranks, init_process_group, rank_env
+    from ..utils.launch import ensure_ranks, init_process_group, rank_env, single_rank_env
     if args.gpus is not None:
         # starts the ranks (fresh child processes) and exits with their code unless this process already is one of them
         ensure_ranks(args.gpus, "clip_feature_codec.cli.eval", argv, module=True)
@@ -190,8 +193,16 @@ def main(argv=None) -> None:
 
     rank, world, _ = rank_env()
     device = pick_device(args.device)
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
+        if world == 1:
+            single_rank_env()
         init_process_group(device)                                 # RCCL; CCN_DIST_BACKEND=gloo for several ranks on one card
+        if args.force_process_group and rank == 0:
+            import sys
+            from ..utils.launch import collective_device
+            print(f"[eval] process group: backend {dist.get_backend()}, world {dist.get_world_size()}, collective on "
+                  f"{collective_device(device).split(':')[0]}", file=sys.stderr)
 
     import sys
     import time
@@ -266,7 +277,7 @@ def main(argv=None) -> None:
                     for i in range(len(manifest))]
             with open(args.out_json, "w", encoding="utf-8") as f:
                 json.dump(recs, f, ensure_ascii=False, indent=2)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

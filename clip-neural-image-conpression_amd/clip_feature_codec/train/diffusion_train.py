@@ -199,7 +199,7 @@ def average_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
 
 
 def train_step(net, sch, opt, x0: torch.Tensor, z: torch.Tensor, t: Optional[torch.Tensor] = None,
-               noise: Optional[torch.Tensor] = None, ddp: bool = False, graph: bool = False) -> torch.Tensor:
+               noise: Optional[torch.Tensor] = None, ddp=False, graph: bool = False) -> torch.Tensor:
     """One optimisation step; returns the (detached) loss.  ``t`` / ``noise`` default to the reference's draws.
 
     All tensors the library touches live at fixed addresses (``TrainState.static_buffers``), so with ``graph=True`` the forward and
@@ -224,8 +224,11 @@ def train_step(net, sch, opt, x0: torch.Tensor, z: torch.Tensor, t: Optional[tor
     state.trainer.forward(fp.flat, sb["x_t"], sb["z"], sb["t"], out=sb["eps"])
     loss, d_eps = _native.mse_loss_grad(sb["eps"], sb["noise"], bufs=(sb["loss"], sb["d_eps"], sb["scratch"]))
     import torch.distributed as dist
-    world = dist.get_world_size() if ddp and dist.is_available() and dist.is_initialized() else 1
-    if world > 1:
+    have_pg = bool(ddp) and dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if have_pg else 1
+    # ddp="always": the bucketed route whenever a process group exists, a one-rank group included (runs the RCCL all-reduces and the
+    # stream joins of the N > 1 route on a single GPU: tests/test_gpu_rccl.py)
+    if world > 1 or (have_pg and ddp == "always"):
         # data parallel: the flat gradient buffer is all-reduced bucket by bucket while the backward still runs (RCCL on its own
         # stream); d_eps is pre-scaled by 1 / world so that the sum is already the mean
         d_eps.mul_(1.0 / world)

@@ -57,12 +57,24 @@ def ensure_ranks(gpus: int, script: str, argv: Optional[Sequence[str]] = None, m
     raise SystemExit(rc)
 
 
+def single_rank_env() -> None:
+    """Rendezvous variables of a one-rank group for a process no launcher started (``--force-process-group``: the collectives of
+    the N > 1 route -- RCCL included -- then run on the one GPU a single-GPU box has)."""
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        os.environ["MASTER_PORT"] = str(free_port())
+
+
 def init_process_group(device: str):
     """RCCL (``backend='nccl'``) on a GPU node; ``CCN_DIST_BACKEND=gloo`` rehearses N > 1 with several ranks on one card."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
         return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the pool's driver only supports dmabuf IPC (RCCL needs it)
     backend = os.environ.get("CCN_DIST_BACKEND", "nccl")
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device(device))

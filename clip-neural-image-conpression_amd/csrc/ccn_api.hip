@@ -9,6 +9,7 @@
 #include "../../include/ccn_hip.h"
 #include "ccn_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,6 +122,7 @@ struct GraphEntry {
     hipGraphExec_t exec = nullptr;
 };
 
+constexpr size_t kMaxGraphsPerPlan = 4;
 struct Plan {
     int B = 0, H = 0, W = 0, steps = 0;
     void* ws = nullptr;
@@ -778,12 +780,16 @@ int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t w
     const int div = 1 << h->cfg.n_mult;
     if (H % div || W % div) return fail(CCN_EINVAL, "H and W must be divisible by 2^len(ch_mult)");
     if (!ws || ((uintptr_t)ws & 255)) return fail(CCN_EWORKSPACE, "workspace must be non-null and 256-byte aligned");
-    for (auto& p : h->plans)
+    for (size_t i = 0; i < h->plans.size(); ++i) {
+        Plan* p = h->plans[i].get();
         if (p->B == B && p->H == H && p->W == W && p->steps == steps && p->ws == ws) {
             if (ws_bytes < p->bytes) return fail(CCN_EWORKSPACE, "workspace too small");
-            *out = p.get();
+            // least recently used first: a hit moves the plan to the back, eviction (below) takes the front
+            std::rotate(h->plans.begin() + (long)i, h->plans.begin() + (long)i + 1, h->plans.end());
+            *out = p;
             return CCN_OK;
         }
+    }
     std::unique_ptr<Plan> p(new Plan);
     p->B = B; p->H = H; p->W = W; p->steps = steps; p->ws = ws;
     int rc = build_plan(h, p.get(), ws, false);
@@ -796,6 +802,20 @@ int get_plan(ccn_handle_s* h, int B, int H, int W, int steps, void* ws, size_t w
     h->plans.push_back(std::move(p));
     return CCN_OK;
 }
+
+}  // namespace
+int ccn_release_workspace(ccn_handle_t h, void* workspace_dev)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    bool any = false;
+    for (auto& p : h->plans) any = any || p->ws == workspace_dev;
+    if (!any) return CCN_OK;
+    HIPCHK(hipDeviceSynchronize());                                 // replays on caller streams may still be using it
+    h->plans.erase(std::remove_if(h->plans.begin(), h->plans.end(), [&](const std::unique_ptr<Plan>& p) { return p->ws == workspace_dev; }),
+                   h->plans.end());
+    return CCN_OK;
+}
+namespace {
 
 // ---- running a plan -------------------------------------------------------------------------------------------
 int ensure_events(ccn_handle_s* h, size_t n)
@@ -1113,7 +1133,20 @@ static int sample_impl(ccn_handle_t h, const float* z_dev, const float* x_T_dev,
             if (ce != hipSuccess) return fail(CCN_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
             g.graph = graph;
             HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            // at most kMaxGraphsPerPlan captured graphs per plan, least recently used first (a caller that passes a fresh noise
+            // tensor / coefficient table every call would otherwise grow the list without bound); an exec may still be replaying
+            // on a caller stream, so the device is drained before one is destroyed
+            if (p->graphs.size() >= kMaxGraphsPerPlan) {
+                HIPCHK(hipDeviceSynchronize());
+                GraphEntry& old = p->graphs.front();
+                if (old.exec) (void)hipGraphExecDestroy(old.exec);
+                if (old.graph) (void)hipGraphDestroy(old.graph);
+                p->graphs.erase(p->graphs.begin());
+            }
             p->graphs.push_back(g);
+            ge = &p->graphs.back();
+        } else if (ge != &p->graphs.back()) {
+            std::rotate(p->graphs.begin() + (ge - p->graphs.data()), p->graphs.begin() + (ge - p->graphs.data()) + 1, p->graphs.end());
             ge = &p->graphs.back();
         }
         HIPCHK(hipGraphLaunch(ge->exec, s));

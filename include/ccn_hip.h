@@ -80,6 +80,14 @@ int ccn_commit_params(ccn_handle_t h);
  * captured graph for it is cached. `steps` = 1 for ccn_forward. */
 int ccn_workspace_bytes(ccn_handle_t h, int32_t B, int32_t H, int32_t W, int32_t steps, size_t* bytes);
 
+/* The caller is about to free (or reuse for something else) a workspace it handed to ccn_forward / ccn_sample: drains the
+ * device, then drops every cached plan and captured graph that lives in it.  The plan cache is keyed by (B, H, W, steps,
+ * workspace address) and a plan keeps state in its workspace between calls (the uploaded timestep table, the zeroed split-K
+ * hand-off flags and arrival counters), so a LATER allocation that lands on the same address must not find the old plan.
+ * Without this call a freed workspace must never be reused at the same address with the same shape.  (No reference
+ * counterpart: torch owns all memory there; this is the ownership rule of SURVEY.md section 8b, "Python owns the workspace".) */
+int ccn_release_workspace(ccn_handle_t h, void* workspace_dev);
+
 /* CLIPCondUNet.forward(x_t, z_clip, t) (models/unet.py:81-106).
  * x_dev (B,img_ch,H,W) fp32 NCHW; z_dev (B,z_dim) fp32; t_dev (B,) int64; eps_dev (B,img_ch,H,W) fp32 NCHW. */
 int ccn_forward(ccn_handle_t h, const float* x_dev, const float* z_dev, const int64_t* t_dev,

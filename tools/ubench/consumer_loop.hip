@@ -257,6 +257,171 @@ static void runk(const char* name, const u32x4* w, unsigned long long* out, floa
     printf("%-44s grid %3d  [%.1f cycles per 24 MFMAs, ideal 768: %.1f %%]\n", name, grid, (double)h[0] / iters, 100.0 * 768 / ((double)h[0] / iters));
 }
 
+// The same wave tile (8 rows x 32 pixels x 32 channels), the same LDS and weight bytes, on the OTHER bf16 MFMA shape:
+// v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The tile is cut into
+// pixel halves p and channel halves c (acc[row][p][c], 4 registers each = the same 128 accumulator registers); one group is a
+// (dx, 32-channel K slice) pair = 6 weight fragments (dy x c) + 20 row fragments (halo row x p) + 96 MFMAs of 16 cycles = TWO groups of
+// the 32x32x16 form (2 x (3 + 10 + 24 x 32 cycles)).  Halo row fragment (hh, p) feeds output rows hh, hh-1, hh-2 x both channel halves the
+// moment it arrives; weights through a ring of two groups (the next group's six loads go out in the six-MFMA steps of this one).
+// F16 = 1: the f16 forms of both shapes (same cycles; what the operand type does to the clock).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// random operand bits, magnitude ~0.25..2 (bf16: 8-bit exponent 125..128; f16: 5-bit exponent 13..16), random sign and mantissa
+__host__ __device__ inline unsigned rnd_pair(unsigned h, int f16, int ebias)
+{
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    if (f16) {
+        const unsigned lo = ((h & 1u) << 15) | ((unsigned)(ebias + 13 + ((h >> 1) & 3u)) << 10) | ((h >> 3) & 0x3ffu);
+        const unsigned hi = (((h >> 13) & 1u) << 15) | ((unsigned)(ebias + 13 + ((h >> 14) & 3u)) << 10) | ((h >> 16) & 0x3ffu);
+        return lo | (hi << 16);
+    }
+    const unsigned lo = ((h & 1u) << 15) | ((unsigned)(ebias + 125 + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 0x7fu);
+    const unsigned hi = (((h >> 10) & 1u) << 15) | ((unsigned)(ebias + 125 + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 0x7fu);
+    return lo | (hi << 16);
+}
+template <int F16> __device__ __forceinline__ void mfma32(f32x16& c, const u32x4& a, const u32x4& b)
+{
+    if (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int F16> __device__ __forceinline__ void mfma16s(f32x4v& c, const u32x4& a, const u32x4& b)
+{
+    if (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// out[0..3] = s_memtime cycles of waves 0-3 of block 0, out[4..7] = s_memrealtime ticks (100 MHz): clock = cycles / ticks * 100 MHz
+// SHAPE 32: the kernel's own loop (kk above) with the operand type a template parameter; SHAPE 16: the 16x16x32 form.
+// `iters` counts 768-cycle units (24 MFMAs of 32x32x16 = 48 of 16x16x32) in both.
+template <int SHAPE, int F16>
+__global__ __launch_bounds__(256) void kshape(const u32x4* __restrict__ w, unsigned long long* out, float* sink, int iters, int rnd)
+{
+    __shared__ u32x4 lds[64 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        u32x4 v = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        if (F16) v = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        if (rnd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = rnd_pair((unsigned)(i * 4 + q) * 2654435761u, F16, 0);
+        }
+        lds[i] = v;
+    }
+    __syncthreads();
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 24, 0x00020000);
+    const int voff = ((blockIdx.x & 3) * 4096 + wave * 1024 + lane) * 16;
+    constexpr int WIN = 6, PF = 4;
+    u32x4 rw[WIN];
+    int sbase = 0;
+    float r = 0.f;
+    unsigned long long t0 = 0, t1 = 0, q0 = 0, q1 = 0;
+    if constexpr (SHAPE == 32) {
+        constexpr int TH = 8, HR = 10, NS = 60;
+        f32x16 acc[TH];
+#pragma unroll
+        for (int m = 0; m < TH; ++m) acc[m] = (f32x16){0};
+        u32x4 bq[3][3];
+        auto rload = [&](int s_) __attribute__((always_inline)) { const int g = (s_ / HR) % 6, hh = s_ % HR; rw[s_ % WIN] = lds[(g & 3) * 1024 + hh * 64 + lane]; };
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) bq[g][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (g * 3 + dy) * 1024, 0));
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) rload(s_);
+        t0 = __builtin_amdgcn_s_memtime(); q0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; it += 6) {
+            sbase = (it & 8) * 1024;
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int g = s_ / HR, hh = s_ % HR;
+                __builtin_amdgcn_sched_barrier(0);
+                const int pg = g + 2;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+                    if (hh == 2 + 2 * dy) bq[pg % 3][dy] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + ((pg % 6) * 3 + dy) * 1024, 0));
+                rload(s_ + PF);
+                int nm = 0;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int i = hh - dy;
+                    if (i >= 0 && i < TH) { mfma32<F16>(acc[i], bq[g % 3][dy], rw[s_ % WIN]); ++nm; }
+                }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (m == 1 && (hh == 2 || hh == 4 || hh == 6)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t1 = __builtin_amdgcn_s_memtime(); q1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int m = 0; m < TH; ++m) r += acc[m][0] + acc[m][7];
+    } else {
+        constexpr int TH = 8, HR = 10, NS = 40;                   // two groups of 20 (halo row, pixel half) steps = 4 units of 768 cycles
+        // one 16-register tuple per output row, the MFMAs work on its quarters (p, c): 32 separate 4-register tuples make the register
+        // allocator permute them over the loop's back edge (~190 v_accvgpr copies per iteration)
+        f32x16 acc[TH];
+#pragma unroll
+        for (int m = 0; m < TH; ++m) acc[m] = (f32x16){0};
+        u32x4 bq[2][3][2];
+        auto rload = [&](int s_) __attribute__((always_inline)) { const int g = (s_ / 20) & 1, hp = s_ % 20; rw[s_ % WIN] = lds[g * 2048 + hp * 64 + lane]; };
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bq[0][dy][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (dy * 2 + c) * 1024, 0));
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) rload(s_);
+        t0 = __builtin_amdgcn_s_memtime(); q0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; it += 4) {
+            sbase = (it & 8) * 1024;
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int g = s_ / 20, hh = (s_ % 20) >> 1, p = s_ & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                // the next group's fragment (dy, c) = hh - 2 goes out in the six-MFMA step (hh, p = 0), hh = 2..7
+                const bool wl = p == 0 && hh >= 2 && hh <= 7;
+                if (wl) {
+                    const int f = hh - 2;
+                    bq[(g + 1) & 1][f >> 1][f & 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sbase + ((((it >> 1) + g + 1) % 3) * 6 + f) * 1024, 0));
+                }
+                rload(s_ + PF);
+                int nm = 0;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int i = hh - dy;
+                    if (i >= 0 && i < TH) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int q = p * 2 + c;
+                            f32x4v t = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                            mfma16s<F16>(t, bq[g & 1][dy][c], rw[s_ % WIN]);
+                            acc[i][4 * q] = t[0]; acc[i][4 * q + 1] = t[1]; acc[i][4 * q + 2] = t[2]; acc[i][4 * q + 3] = t[3];
+                            ++nm;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (m == 2 && wl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (m == 1 || m == 3 || m == 5) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t1 = __builtin_amdgcn_s_memtime(); q1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int m = 0; m < TH; ++m) r += acc[m][0] + acc[m][7] + acc[m][9] + acc[m][14];
+    }
+    if (lane == 0 && blockIdx.x == 0) { out[wave] = t1 - t0; out[4 + wave] = q1 - q0; }
+    sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 // Co-execution: waves 0-3 run the kernel-order consumer loop (kk), waves 4-7 (one per SIMD, like the producers) issue VALU
 // work until the consumers finish: VPI VALU instructions, then a sleep of GAP*64 cycles, repeated.  How many VALU instructions
 // fit next to a group of 24 MFMAs, and what does each cost the MFMA stream?
@@ -470,6 +635,20 @@ static void runsym(unsigned long long* out, float* sink)
     printf("symmetric: %d wave(s) per SIMD, %d v_fma after each MFMA: %.1f cycles per MFMA on the SIMD (%.1f %% of the MFMA rate), %d VALU per MFMA\n", WPS, NV, cyc, 3200.0 / cyc, NV);
 }
 
+static void fill_w(u32x4* w, int f16)
+{
+    std::vector<unsigned> hw((1 << 24) / 4);
+    unsigned st = 12345u;
+    for (auto& x : hw) { st = st * 1664525u + 1013904223u; x = rnd_pair(st ^ (st >> 13), f16, -3); }
+    (void)hipMemcpy(w, hw.data(), 1 << 24, hipMemcpyHostToDevice);
+}
+static void report_clock(unsigned long long* out, int iters)
+{
+    unsigned long long h[8]; (void)hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    printf("    in-kernel: %.1f cycles per 768-cycle unit (%.1f %% of the MFMA rate), clock %.3f GHz\n", (double)h[0] / iters, 100.0 * 768 * iters / (double)h[0],
+           (double)h[0] / (double)h[4] * 0.1);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) {
@@ -499,6 +678,46 @@ int main(int argc, char** argv)
         else if (v == "loop_lds_only") spin([&] { hipLaunchKernelGGL((kg<8, 10, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters); }, sec);
         else if (v == "loop_w_only") spin([&] { hipLaunchKernelGGL((kg<8, 0, 3>), dim3(256), dim3(256), 0, 0, w, out, sink, iters); }, sec);
         else if (v == "loop_sibling") spin([&] { hipLaunchKernelGGL((kco<1, 0, 0>), dim3(256), dim3(512), 0, 0, w, out, sink, iters, 0); }, sec);
+        else if (v == "loop_rnd16" || v == "loop16" || v == "loop_rnd_f16" || v == "loop_rnd16_f16" || v == "loop32") {
+            // one shape / operand type on all CUs (power_probe_ubench.sh samples rocm-smi beside it)
+            const int f16 = v.find("f16") != std::string::npos, rnd = v.find("rnd") != std::string::npos, s16 = v.find("16") != std::string::npos && v != "loop_rnd_f16";
+            if (rnd) fill_w(w, f16);
+            auto launch = [&] {
+                if (s16 && f16) hipLaunchKernelGGL((kshape<16, 1>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, rnd);
+                else if (s16) hipLaunchKernelGGL((kshape<16, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, rnd);
+                else if (f16) hipLaunchKernelGGL((kshape<32, 1>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, rnd);
+                else hipLaunchKernelGGL((kshape<32, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, rnd);
+            };
+            spin(launch, sec);
+            report_clock(out, iters);
+        }
+        else if (v == "shape_ab") {
+            // rule 24: the variants interleaved in ONE process on one device, several rounds; random operands (rule 25); cycles AND wall AND clock
+            const char* names[4] = {"32x32x16 bf16", "16x16x32 bf16", "32x32x16 f16 ", "16x16x32 f16 "};
+            const int rounds = argc > 3 ? atoi(argv[3]) : 4;
+            fill_w(w, 0);
+            spin([&] { hipLaunchKernelGGL((kshape<32, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1); }, 2.0);   // warm: clocks settle under load
+            for (int rd = 0; rd < rounds; ++rd)
+                for (int k = 0; k < 4; ++k) {
+                    fill_w(w, k >> 1);
+                    printf("round %d  %s  ", rd, names[k]);
+                    auto launch = [&] {
+                        if (k == 0) hipLaunchKernelGGL((kshape<32, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1);
+                        if (k == 1) hipLaunchKernelGGL((kshape<16, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1);
+                        if (k == 2) hipLaunchKernelGGL((kshape<32, 1>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1);
+                        if (k == 3) hipLaunchKernelGGL((kshape<16, 1>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 1);
+                    };
+                    spin(launch, sec);
+                    report_clock(out, iters);
+                }
+            // zero-toggle control: constants rank the shapes by cycles only (give-back item 7)
+            for (int k = 0; k < 2; ++k) {
+                printf("constants %s  ", names[k]);
+                spin([&] { if (k == 0) hipLaunchKernelGGL((kshape<32, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 0);
+                           else hipLaunchKernelGGL((kshape<16, 0>), dim3(256), dim3(256), 0, 0, w, out, sink, iters, 0); }, sec);
+                report_clock(out, iters);
+            }
+        }
         else { printf("unknown variant\n"); return 1; }
         return 0;
     }
