@@ -238,30 +238,23 @@ def main() -> None:
             p16 = [psnr(orig[k], r16[k]) for k in range(B)]
             p32 = [psnr(orig[k], r32[k]) for k in range(B)]
             rel = [abs(a - b) / abs(b) for a, b in zip(p16, p32)]
-            # the same comparison against fp32 ARITHMETIC on the weights bf16 mode actually holds (conv weights rounded to bf16,
-            # what a checkpoint stored in bf16 -- or the reference's autocast -- gives the fp32 path): separates the error of
-            # this library's bf16 arithmetic from the precision the weights are stored in
             del net32
-            net32r = CLIPCondUNet(512, args.base, ch_mult, dtype="fp32").to(dev).eval()
-            net32r.load_state_dict({k: (torch.from_numpy(v).to(torch.bfloat16).float() if v.ndim == 4 else torch.from_numpy(v))
-                                    for k, v in sd.items()}, strict=True)
-            r32r = sampler.sample(net32r, z, (B, 3, S, S), steps=T, x_T=x_T).clamp(-1, 1).cpu().numpy()
-            p32r = [psnr(orig[k], r32r[k]) for k in range(B)]
-            relr = [abs(a - b) / abs(b) for a, b in zip(p16, p32r)]
-            del net32r
             parity["psnr_vs_synthetic_originals"] = {
                 "records": B, "psnr_fp32_mode_mean_db": round(float(np.mean(p32)), 4), "psnr_bf16_mean_db": round(float(np.mean(p16)), 4),
                 "max_rel_delta": float(max(rel)), "mean_rel_delta": float(np.mean(rel)),
                 "rel_delta_of_means": float(abs(np.mean(p16) - np.mean(p32)) / abs(np.mean(p32))),
                 "gate_rel": 1e-3, "pass": bool(max(rel) <= 1e-3),
-                "vs_fp32_arithmetic_on_bf16_rounded_weights": {
-                    "psnr_mean_db": round(float(np.mean(p32r)), 4), "max_rel_delta": float(max(relr)), "mean_rel_delta": float(np.mean(relr)),
-                    "gate_rel": 1e-3, "pass": bool(max(relr) <= 1e-3),
-                    "note": "the shift against full-precision weights comes from rounding the WEIGHTS to bf16 (a static change of the "
-                            "model, shared by any bf16 implementation), not from this library's bf16 arithmetic"}}
+                "weight_rounding": "error-diffused bf16 (ccn_set_weight_rounding default; independent rounding measures 0.165 % max)"}
         else:
             del net32
         del x32
+
+    quality_gate_met = None
+    if parity is not None:
+        if "psnr_vs_synthetic_originals" in parity:
+            quality_gate_met = bool(parity["psnr_vs_synthetic_originals"]["pass"])
+        elif "fp32_mode_row0_vs_reference_cpu" in parity and args.dtype == "fp32":
+            quality_gate_met = bool(parity["fp32_mode_row0_vs_reference_cpu"]["pass"])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -306,6 +299,9 @@ def main() -> None:
                        ("value_with_two_steps_in_flight" if nfl == 1 else "value_with_one_step_in_flight"): other_value},
             "rccl_ranks": ranks_seen, "backend": (dist.get_backend() if use_pg else None),
             "per_rank_images_per_sec": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)},
+            # north_star's quality gate for the timed mode, on the timed batch: PSNR within 0.1 % of the reference-equivalent fp32 path per
+            # record (bf16), or the 1e-3 max-abs gate against the reference's CPU run (fp32); null when the parity block was skipped
+            "quality_gate_met": quality_gate_met,
             "roofline": roofline, "parity": parity, "parity_mode": parity_mode, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

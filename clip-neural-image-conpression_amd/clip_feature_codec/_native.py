@@ -35,6 +35,7 @@ SIGNATURES = {
     "ccn_param_info": (c_i32, [c_vp, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), ctypes.POINTER(c_i32)]),
     "ccn_load_param": (c_i32, [c_vp, ctypes.c_char_p, c_vp, ctypes.POINTER(c_i64), c_i32]),
     "ccn_commit_params": (c_i32, [c_vp]),
+    "ccn_set_weight_rounding": (c_i32, [c_vp, c_i32]),
     "ccn_workspace_bytes": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_sz)]),
     "ccn_release_workspace": (c_i32, [c_vp, c_vp]),
     "ccn_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
@@ -147,7 +148,7 @@ class NativeUNet:
     MAX_WORKSPACES = 8
 
     def __init__(self, z_dim: int, base: int, ch_mult: Sequence[int], time_dim: int, img_ch: int,
-                 groups: int = 8, dtype="fp32", device="cuda") -> None:
+                 groups: int = 8, dtype="fp32", device="cuda", weight_rounding: str = "diffused") -> None:
         self.lib = load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -160,6 +161,9 @@ class NativeUNet:
         with torch.cuda.device(self.device):
             check(self.lib.ccn_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
+        if weight_rounding not in ("nearest", "diffused"):
+            raise ValueError("weight_rounding must be 'nearest' or 'diffused'")
+        check(self.lib.ccn_set_weight_rounding(self.h, 1 if weight_rounding == "diffused" else 0))
         self._ws: Dict[Tuple[int, int, int, int, int], Workspace] = {}
 
     def close(self) -> None:

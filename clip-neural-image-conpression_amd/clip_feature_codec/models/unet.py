@@ -58,10 +58,12 @@ class CLIPCondUNet(nn.Module):
     """FiLM-conditioned pixel-space U-Net, epsilon prediction."""
 
     def __init__(self, z_dim: int = 512, base: int = 128, ch_mult: Tuple[int, ...] = (1, 2, 2),
-                 time_dim: int = 256, img_ch: int = 3, dtype: str = "fp32") -> None:
+                 time_dim: int = 256, img_ch: int = 3, dtype: str = "fp32", weight_rounding: str = "diffused") -> None:
         super().__init__()
         self.arch = dict(z_dim=z_dim, base=base, ch_mult=tuple(ch_mult), time_dim=time_dim, img_ch=img_ch)
         self.compute_dtype = dtype
+        # bf16 mode only: "diffused" (error-diffused rounding of the conv weights, ccn_set_weight_rounding) or "nearest"
+        self.weight_rounding = weight_rounding
         # parameter containers, registered in the reference's order (same keys, same RNG consumption)
         self.time_proj = nn.Sequential(nn.Linear(time_dim, time_dim * 4), nn.SiLU(), nn.Linear(time_dim * 4, time_dim))
         self.z_proj = nn.Sequential(nn.Linear(z_dim, time_dim), nn.SiLU())
@@ -117,13 +119,14 @@ class CLIPCondUNet(nn.Module):
         # counter (bumped by FusedAdamW.step) is part of the key, the views' own counters do not move
         st = getattr(self, "_train_state", None)
         flat_version = st.fp.flat._version if st is not None and st.fp.intact() else None
-        key = (str(dev), self.compute_dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params), flat_version)
+        key = (str(dev), self.compute_dtype, self.weight_rounding, tuple(p._version for p in params), tuple(p.data_ptr() for p in params),
+               flat_version)
         if self._nat is None or self._nat_key != key:
             if self._nat is not None:
                 self._nat.close()
             a = self.arch
             nat = _native.NativeUNet(a["z_dim"], a["base"], a["ch_mult"], a["time_dim"], a["img_ch"], groups=8,
-                                     dtype=self.compute_dtype, device=dev)
+                                     dtype=self.compute_dtype, device=dev, weight_rounding=self.weight_rounding)
             nat.load_state_dict(self.state_dict())
             self._nat, self._nat_key = nat, key
         return self._nat

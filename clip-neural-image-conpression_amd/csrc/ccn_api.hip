@@ -166,6 +166,7 @@ struct ccn_handle_s {
     float* head_w_f32 = nullptr;       // (img_ch, C, 3, 3) fp32 copy of out.weight for the dedicated head kernel
     int F = 0;                          // rows of the concatenated FiLM linear
     int G = 8;
+    int weight_rounding = CCN_ROUND_DIFFUSED;   // how bf16 mode rounds the conv weights in ccn_commit_params (ccn_set_weight_rounding)
     std::vector<std::unique_ptr<Plan>> plans;
     hipStream_t cap_stream = nullptr;
     unsigned* err_host = nullptr;       // pinned, device-mapped error word the kernels OR into (ConvArgs::err)
@@ -253,6 +254,56 @@ int upload_f32(ccn_handle_s* h, const std::string& name, float** dst)
     return upload(h, v.data(), v.size() * 4, (void**)dst);
 }
 
+float bf16_value(float f)
+{
+    const uint32_t u = (uint32_t)f2bf_host(f) << 16;
+    float r;
+    std::memcpy(&r, &u, 4);
+    return r;
+}
+
+// bf16 mode, CCN_ROUND_DIFFUSED: the conv weights are rounded to bf16 with ERROR DIFFUSION along the contraction of every output
+// channel instead of independently (round-to-nearest-even): walking (cin, ky, kx) with kx fastest, each element is rounded after
+// the accumulated rounding error of its predecessors has been added to it, so that every partial sum of an output channel's
+// weights -- over the taps of one input channel, over input channels -- stays within half an ulp of the fp32 sum.  Independent
+// rounding perturbs the model statically: the response of each conv to the smooth / mean part of its input shifts by a random
+// walk over K = 9 Cin roundings, the same way in all 50 steps, and the reconstructions lose 0.33 % contrast (+0.11 % PSNR against
+// the fp32 mode, above north_star's 0.1 % gate; tools/weight_rounding_probe.py, profiles/r03_weight_rounding_probe.txt).  With
+// diffusion the same bf16 kernels land within 0.04 % mean / 0.075 % max.  Costs nothing at run time: the values are ordinary bf16.
+// The weights are replaced IN PLACE by bf16-representable fp32 values, so every packer below rounds them exactly.
+// ConvTranspose2d (Cin, Cout, 4, 4): an output pixel of parity (py, px) sees only 4 of the 16 taps (ky in {1,3} or {0,2}), so the
+// diffusion runs per (output channel, parity) over (cin, those 4 taps).
+void diffuse_round_conv(std::vector<float>& w, int O, int I, int taps)        // Conv2d (O, I, k, k)
+{
+    for (int o = 0; o < O; ++o) {
+        double err = 0.0;
+        float* row = w.data() + (size_t)o * I * taps;
+        for (size_t k = 0; k < (size_t)I * taps; ++k) {
+            const double t = (double)row[k] + err;
+            const float r = bf16_value((float)t);
+            err = t - (double)r;
+            row[k] = r;
+        }
+    }
+}
+void diffuse_round_convT(std::vector<float>& w, int I, int O)                 // ConvTranspose2d (I, O, 4, 4), stride 2, padding 1
+{
+    static const int kk2[2][2] = {{1, 3}, {0, 2}};                            // kernel indices feeding even / odd outputs (fill_taps)
+    for (int o = 0; o < O; ++o)
+        for (int par = 0; par < 4; ++par) {
+            double err = 0.0;
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 4; ++t) {
+                    const int wt = kk2[par >> 1][t >> 1] * 4 + kk2[par & 1][t & 1];
+                    float& v = w[((size_t)i * O + o) * 16 + wt];
+                    const double tt = (double)v + err;
+                    const float r = bf16_value((float)tt);
+                    err = tt - (double)r;
+                    v = r;
+                }
+        }
+}
+
 // element (tap, o, i) of the packed [taps][Cout_pad][Cin_pad] tensor
 template <typename F>
 int pack_and_upload(ccn_handle_s* h, ConvW& cw, int taps, F&& at)
@@ -305,30 +356,14 @@ int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2
                                 }
         if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
     }
-    if (cw.kind == KIND_C3S1 && cw.BN == 128) {
-        // fragment order for ccn_conv_pr.hip: [chunk][Cout_pad/32][tap][kk][lane = h*32 + r][EPC]; lane (r, h) of column n32
-        // holds output channel n32*32 + r, input channels chunk*cke + (2*kk + h)*EPC + e -- one wave load = 1 KiB contiguous
-        const int epc = cke / 8, nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32, O = cw.Cout;
-        const size_t n = (size_t)nch * n32 * 9 * 4 * 64 * epc;
-        std::vector<float> tmp(n, 0.f);
-        size_t p = 0;
-        // step j of a chunk = (dx = j/12, k-slice kk = (j/3)%4, dy = j%3): the kernel walks the taps column by column so that one
-        // LDS address serves the three dy taps (ccn_conv_pr.hip)
-        for (int c = 0; c < nch; ++c)
-            for (int nn = 0; nn < n32; ++nn)
-                for (int j = 0; j < 36; ++j)
-                    for (int ln = 0; ln < 64; ++ln)
-                        for (int e = 0; e < epc; ++e, ++p) {
-                            const int dx = j / 12, kk = (j / 3) % 4, dy = j % 3, t = dy * 3 + dx;
-                            const int o = nn * 32 + (ln & 31), i = c * cke + (2 * kk + (ln >> 5)) * epc + e;
-                            tmp[p] = (o < O && i < I) ? w[((size_t)o * I + i) * 9 + t] : 0.f;
-                        }
-        if (h->cfg.dtype == CCN_DTYPE_BF16) {
-            std::vector<uint16_t> b16(n);
-            for (size_t q = 0; q < n; ++q) b16[q] = f2bf_host(tmp[q]);
-            rc = upload(h, b16.data(), n * 2, &cw.wfrag);
-        } else rc = upload(h, tmp.data(), n * 4, &cw.wfrag);
-        if (rc) return rc;
+    if (cw.kind == KIND_C3S1 && cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
+        // fragment order of the persistent kernel's 3x3 form (pr3_frag_index, ccn_internal.h): one wave load = 1 KiB contiguous
+        const int nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32, O = cw.Cout;
+        std::vector<uint16_t> fr((size_t)nch * n32 * 36 * 64 * 8, 0);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) fr[pr3_frag_index(o, i, t, cw.Cout_pad)] = f2bf_host(w[((size_t)o * I + i) * 9 + t]);
+        if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
     }
     return upload_f32(h, name + ".bias", &cw.bias);
 }
@@ -999,6 +1034,14 @@ int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const in
     return CCN_OK;
 }
 
+int ccn_set_weight_rounding(ccn_handle_t h, int32_t mode)
+{
+    if (!h) return fail(CCN_EINVAL, "null handle");
+    if (mode != CCN_ROUND_NEAREST && mode != CCN_ROUND_DIFFUSED) return fail(CCN_EINVAL, "unknown weight rounding mode");
+    h->weight_rounding = mode;
+    return CCN_OK;
+}
+
 int ccn_commit_params(ccn_handle_t h)
 {
     if (!h) return fail(CCN_EINVAL, "null handle");
@@ -1011,6 +1054,16 @@ int ccn_commit_params(ccn_handle_t h)
     h->dev_allocs.clear();
     const ccn_config_t& c = h->cfg;
     int rc;
+    if (c.dtype == CCN_DTYPE_BF16 && h->weight_rounding == CCN_ROUND_DIFFUSED) {
+        // (the head keeps fp32 weights: head_prep_kernel scales them per sample before rounding)
+        for (auto& p : h->params) {
+            if (p.shape.size() != 4 || p.name == "out.weight") continue;
+            auto& w = h->host.at(p.name);
+            const bool convT = p.shape[2] == 4;                               // up.N.weight: (Cin, Cout, 4, 4)
+            if (convT) diffuse_round_convT(w, (int)p.shape[0], (int)p.shape[1]);
+            else diffuse_round_conv(w, (int)p.shape[0], (int)p.shape[1], (int)(p.shape[2] * p.shape[3]));
+        }
+    }
     h->stem = ConvW(); h->stem.kind = KIND_STEM; h->stem.Cin = c.img_ch; h->stem.Cout = c.base;
     if ((rc = pack_stem(h, h->stem, "in_conv"))) return rc;
     for (auto& r : h->res) {

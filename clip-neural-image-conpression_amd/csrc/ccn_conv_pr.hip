@@ -24,10 +24,10 @@
 //   * the consumers, idle until the first chunk is in LDS, stage the lower half of its halo rows themselves; the LAST tile's
 //     bias / FiLM / residual operands are fetched before the final barrier of the chunk loop;
 //   * TH = 4: the same kernel on 4-row tiles for layers with fewer than #CUs 8-row tiles.
-// Built, measured in product builds and compiled OUT (flags keep them reproducible): the last tile's epilogue split between the
-// two roles (-DCCN_AB_COOP_TAIL: +-1 % by box), write-through output stores (-DCCN_AB_SC1_STORES: -1..-2 %).  Built, measured and REMOVED:
-// blocked tile order with staged input kept in LDS between neighbouring tiles (-3..-4 %: DESIGN.md section 4, finding 12; last present in
-// commit ab3fdf7).
+// Built, measured in product builds and REMOVED (DESIGN.md / docs/EXPERIMENTS.md keep the numbers and the last commit that carries each):
+// the last tile's epilogue split between the two roles (+-1 % by box), write-through output stores (-1..-2 %), blocked tile order with
+// staged input kept in LDS between neighbouring tiles (-3..-4 %), a deeper weight ring, runtime split-K / GroupNorm-source switches.
+// Round 3: the 3x3 consumers moved from v_mfma_f32_32x32x16_bf16 to v_mfma_f32_16x16x32_bf16 (same tile, same bytes, higher clock).
 // Tile: TH (8 or 4) rows x 32 pixels x 128 output channels, 4 consumer waves (3x3: all rows x 32 channels each; other tap sets:
 // 2x2 waves of 4x2 fragments of 32x32) + 4 producer waves.
 // Rounding: the conv accumulator is rounded to bf16 once before the affine/residual and the sum once more on store
@@ -46,11 +46,7 @@ namespace {
 // x / d for a divisor known at launch: d's magic number m = ceil(2^32 / d) comes in the launch arguments (0 for d == 1), the quotient
 // is one v_mul_hi_u32 instead of the ~40-instruction float-reciprocal sequence of a runtime integer division -- a tile decode has five
 // of them and the producers, the pole of the 128-channel layers, decode two tiles' worth per tile.  Exact while x * d < 2^32.
-#ifdef CCN_AB_SLOW_DIV
-#define CCN_FDIV(x, m, d) ((int)(x) / (int)(d))
-#else
 #define CCN_FDIV(x, m, d) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))
-#endif
 
 template <int TH_> struct PrLdsT {
     static constexpr int HROWS = TH_ + 2, HPITCH = 34;
@@ -86,7 +82,6 @@ template <int NTAPS, int D, int MODE, int TH = 8, int GS = 0>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
     static_assert(TH == 8 || (TH == 4 && NTAPS == 9), "4-row tiles: 3x3 stride-1 form only");
-    constexpr bool COLW = true;                                // 3x3: column-per-wave consumers (false: the 4x2 fragment form)
     constexpr bool RES = MODE == 1;                            // residual registers: MODE 1 always, MODE 2 in the second K half
     constexpr bool RR = MODE != 0;
     typedef __bf16 T;
@@ -127,11 +122,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto vt = [&](int ti) __attribute__((always_inline)) { return vb + ti * grid; };
     // split-K launches run the MODE 2 instantiation only (launch_conv_pr): everywhere else ks folds to 1 at compile time and the
     // hand-off branches of the epilogue disappear
-#ifdef CCN_AB_RUNTIME_KS
-    const int ks = a.ksplit == 2 ? 2 : 1;
-#else
     const int ks = (MODE == 2 && a.ksplit == 2) ? 2 : 1;
-#endif
     const int nck = a.nchunk / ks;                             // chunks per virtual tile
     const int ktotal = my_tiles * nck;
     auto vt_tile = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v >> 1) : v; };
@@ -140,24 +131,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     const unsigned char* const inb = (const unsigned char*)a.in;
     // GroupNorm of the input: scale/shift per (sample, channel) either from the table a separate finalize launch wrote (gn_ab),
     // or -- gs_part != null -- formed HERE from the producing kernel's partial sums (no finalize launch between two convs)
-#ifdef CCN_AB_RUNTIME_GS
-    const bool gstat = NTAPS == 9 && MODE != 2 && a.gs_part != nullptr;       // (3x3 stride-1 layers without split-K only)
-#else
     constexpr bool gstat = GS == 1;                                           // (launch_conv_pr: GS == 1 exactly when a.gs_part is set)
     static_assert(GS != 1 || (NTAPS == 9 && MODE != 2), "in-kernel statistics: 3x3 stride-1 layers without split-K");
-#endif
     // (the ConvTranspose / stride-2 forms never have a GroupNorm on their input -- launch_conv_pr refuses it -- so the transform and
     // its coefficient traffic compile out of those instantiations)
-#ifdef CCN_AB_RUNTIME_GN
-    const bool gn = (a.gn_ab != nullptr || gstat) && !CCN_DBG_BIT(a, 32);     // CCN_DBG=32: skip the transform (timing experiments only)
-#else
-#ifdef CCN_AB_RUNTIME_GS
-    const bool gn = NTAPS == 9 && (a.gn_ab != nullptr || gstat) && !CCN_DBG_BIT(a, 32);
-#else
     // GS: 0 = scale / shift table (a.gn_ab), 1 = formed here from partial sums, 2 = no GroupNorm on the input (pre-activated input)
     const bool gn = NTAPS == 9 && GS != 2 && !CCN_DBG_BIT(a, 32);
-#endif
-#endif
     constexpr unsigned OOB = 0x7FFFFFF0u;
     auto raw_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -183,17 +162,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
     stamp(0);
 
-    // ---- epilogue machinery (role-neutral: the producers run it for every tile, and the consumers join them for the LAST tile of
-    // the launch, whose epilogue nothing overlaps).  thread -> fixed channel octet o16 of the tile's 128, pixels pr + 16*it
+    // ---- epilogue machinery (run by the producer waves).  thread -> fixed channel octet o16 of the tile's 128, pixels pr + 16*it
     // (it < 2 TH) of its 32 TH: row it>>1, column pr + 16*(it&1); residual rows, bias and FiLM are fetched during the tile's last chunk
     const int etid = tid & 255, ew = wave & 3;
     const int o16 = etid & 15, pr = etid >> 4;
     unsigned char* const outb = (unsigned char*)a.out;
     const unsigned char* const resb = (const unsigned char*)a.res;
     const unsigned out_bytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(T));
-    // per-wave channel sums of an epilogue: producer waves behind the staging tile; consumer waves (last tile only) at the start
-    // of the input buffers, which nobody touches after the final barrier of the chunk loop
-    float* const chs = (float*)(wave >= 4 ? stg + L::STG_BYTES : smem) + ew * 256;
+    // per-wave channel sums of an epilogue, behind the staging tile
+    float* const chs = (float*)(stg + L::STG_BYTES) + ew * 256;
     constexpr int NQ = TH / 2;               // epilogue batches of 4 items (two tile rows each)
     u32x4 rr[RR ? 2 : 1][4];                 // residual rows, batches of 4 items (two tile rows), two batches in flight
     f32x4 fb[2], fs[RES ? 1 : 2], ft[RES ? 1 : 2];   // raw bias / FiLM scale / FiLM shift of this thread's octet
@@ -246,11 +223,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                    #ifdef CCN_AB_PLAIN_RES
-    if (false) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);
-#else
-    if (!CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt: read once (+0.6 %)
-#endif
+                        if (!CCN_DBG_BIT(a, 16384)) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 2);   // nt: read once (+1.2 %)
                         else dst[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, item_off(eb, q * 4 + i), 0, 0);
                     }
                 }
@@ -345,15 +318,9 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                         }
                     }
                 }
-                // Plain (write-back) output stores.  Write-through (sc1) stores leave nothing dirty for the end-of-kernel release to
-                // flush and looked 2 % faster in the diagnostics build; in product builds they are 1-2 % SLOWER on every box tried
-                // (the next conv then reads its input from beyond L2), so they stay behind -DCCN_AB_SC1_STORES.
-#ifndef CCN_AB_SC1_STORES
-                if (true) __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
-#else
-                if (first || CCN_DBG_BIT(a, 2048)) __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
-#endif
-                else __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 16);
+                // Plain (write-back) output stores: write-through (sc1) stores are 1-2 % slower in product builds (the next conv then
+                // reads its input from beyond L2)
+                __builtin_amdgcn_raw_buffer_store_b128(Vec16<T>::pack(x), osrd_c, off, 0, 0);
                 if (live) {                                           // exec-masked: costs scalar ops, not 8 VALU multiplies
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
@@ -389,8 +356,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // (tile, group) -- a quarter of the slots a per-wave publication needs, which is what lets the consuming conv reduce
     // them itself in one round of loads (stats()).  Wave ew takes every fourth group of the tile's channel range;
     // fixed summation order (lane tree), so the statistics stay run-to-run deterministic.
-    // `areas` = 4, or 8 for the last tile when the consumer waves took half of its epilogue.
-    auto combine = [&](int areas) __attribute__((always_inline)) {
+    auto combine = [&]() __attribute__((always_inline)) {
         if (!pd_on) return;
         pd_on = false;
         const float* const all = (const float*)(stg + L::STG_BYTES);
@@ -402,25 +368,14 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int clo = max(g * a.cpg, n0), chi = min((g + 1) * a.cpg, nend);
             float t1 = 0.f, t2 = 0.f;
             const float* const wa = all + (lane >> 4) * 256;
-            const float* const wc = (const float*)smem + (lane >> 4) * 256;
             for (int c = clo + (lane & 15); c < chi; c += 16) {
                 t1 += wa[(c - n0) * 2]; t2 += wa[(c - n0) * 2 + 1];
-                if (areas == 8) { t1 += wc[(c - n0) * 2]; t2 += wc[(c - n0) * 2 + 1]; }
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
             if (lane == 0) part_store(a.part + (size_t)(pd_b * a.G + g) * a.nslot + pd_slot, t1, t2);
         }
     };
-
-    // The last tile of the launch: its epilogue overlaps nothing (the consumers are done), so both roles CAN run half of it each --
-    // producers the first TH/2 rows, consumers the rest -- and meet at one more barrier for the statistics (not under split-K: its
-    // hand-off flags are per producer wave).  Measured +0.5 % on one box, -1.3 % on another, 0 on a third: off in the product build.
-#ifndef CCN_AB_COOP_TAIL
-    const bool coop_tail = false;
-#else
-    const bool coop_tail = ks == 1 && !CCN_DBG_BIT(a, 1024);
-#endif
 
     // ---- input staging machinery (role-neutral like the epilogue's: the producers run it for every chunk; the consumers,
     // idle until the first chunk is in LDS, stage the lower half of the halo rows of that first chunk themselves)
@@ -589,7 +544,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         for (int i = 0; i < AIT; ++i) {
             if (i < HROWS ? (i < r0 || i >= r1) : !with_x) continue;
             const int px = i < HROWS ? i * HPITCH + pc : (pc >> 1) * HPITCH + 32 + (pc & 1);
-            const int sw = i < HROWS ? (pc >> 1) : 0;                    // extra item: columns 32, 33 -> (hx >> 1) & 7 == 0
+            // 3x3 form (16x16x32 MFMA): slices swizzled by (hx >> 1) & 3; the 4-tap / 2-tap forms (32x32x16): by (hx >> 1) & 7
+            const int sw = i < HROWS ? (NTAPS == 9 ? (pc >> 1) & 3 : (pc >> 1)) : 0;   // extra item: columns 32, 33 -> swizzle 0
             u32x4 v = areg[i];
             const bool ok = i < HROWS ? (((rowm >> i) & 1u) && colv) : xv;
             if (gn) {
@@ -603,11 +559,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     };
 
     // first chunk of the launch: halo rows [0, HSPLIT) + the extra columns by the producers, [HSPLIT, HROWS) by the consumers
-#ifdef CCN_NO_COOP_HEAD
-    constexpr int HSPLIT = HROWS;                                  // A/B build: producers stage all of it
-#else
     constexpr int HSPLIT = HROWS / 2;
-#endif
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers (4 waves): input chunks + tile epilogues
@@ -615,9 +567,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // transcendental, next to a consumer wave that owns the SIMD's issue priority), so the per-item address math is
         // reduced to one add: item i of a thread is halo row i at a fixed column, offsets are base + i * row stride, row
         // validity is wave-uniform, and everything is branch-free (out-of-range offsets make loads return zero).
-#ifdef CCN_AB_PPRIO
-        __builtin_amdgcn_s_setprio(CCN_AB_PPRIO);                    // A/B build: static producer priority
-#endif
         // the producers outrank the consumers (priority 2) where THEY are the pole (launch_conv_pr decides per layer)
         if (a.prod_first) __builtin_amdgcn_s_setprio(3);
         if (CCN_DBG_BIT(a, 128)) __builtin_amdgcn_s_setprio(1);      // diagnostics: producer priority experiments
@@ -634,10 +583,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_w += t1 - t0; t0 = t1;
             }
-#ifdef CCN_AB_PROD_IDLE
-            // timing experiment (wrong results): the producers only keep the barrier protocol -> the consumers' speed with nothing next to them
-            timed_barrier(); if (++c == nck) { c = 0; ++ti; } continue;
-#endif
             if (k + 1 < ktotal) { prep(); dump((k + 1) & 1); }
             if (CCN_STAMPS_PTR(a)) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_a += t1 - t0; t0 = t1; }
             const bool epi = c == 0 && ti > 0;                     // previous tile: its staging was complete at the last barrier
@@ -652,47 +597,44 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             // final barrier where nothing hides their latency.  (The second half of a split-K pair first has to see its
             // partner's flag; that wait stays behind the barrier so that it cannot hold this workgroup's consumers up.)
             const bool early = k + 1 == ktotal && !(ks == 2 && e_kh == 1);
-            if (early) epi_request(0, coop_tail ? NQ / 2 : NQ);
+            if (early) epi_request(0, NQ);
             timed_barrier();                                       // chunk k+1 visible, chunk k released, staging complete
-            combine(4);                                            // (the sums of an epilogue that ran in this iteration)
+            combine();                                             // (the sums of an epilogue that ran in this iteration)
             if (++c == nck) { c = 0; ++ti; }
         }
         if (ks == 2 && e_kh == 1) epi_request(0, NQ);
-        if (coop_tail) epilogue(0, NQ / 2); else epilogue(0, NQ);  // last tile (the consumers take the other half)
+        epilogue(0, NQ);                                           // last tile
         if (pd_on) {
-            // all eight waves when the tail is shared; else the consumers have left (or are leaving) the kernel and the barrier
-            // waits for the surviving waves only, i.e. the four producers
+            // the consumers have left (or are leaving) the kernel: the barrier waits for the surviving waves only, the four producers
             raw_barrier();
-            combine(coop_tail ? 8 : 4);
+            combine();
         }
         stamp(2); stamp_cycles();
         return;
     }
 
     // ---------------------------------------------------------------------- consumers (4 waves)
-#ifndef CCN_AB_NO_CPRIO
     if (!CCN_DBG_BIT(a, 16)) __builtin_amdgcn_s_setprio(2);
-#endif
-    if constexpr (NTAPS == 9 && COLW) {
-        // 3x3, column-per-wave form: wave w owns ALL 8 tile rows of the 32 output channels nt*128 + 32w.  Per (dx, k-slice)
-        // group it needs 3 weight fragments (one per dy) -- half the L1 traffic of the 4x2 form, whose row pairs fetched the
-        // same weights twice -- and the 10 halo rows of that column/slice, each read ONCE from LDS and used for up to three
-        // (output row, dy) pairs the moment it arrives (row hh feeds output rows hh, hh-1, hh-2), so only the prefetch window is live.
-#ifndef CCN_AB_PF
-#define CCN_AB_PF 4
-#endif
-#ifndef CCN_AB_DG
-#define CCN_AB_DG 3
-#endif
-        constexpr int WIN = 6, PF = CCN_AB_PF;                     // row-fragment window / prefetch distance (rows)
-        constexpr int DG = CCN_AB_DG;                              // weight ring depth in groups (prefetch distance DG-1 groups = 48 MFMAs)
-        constexpr int NG = 12, NROW = HROWS;
-#ifdef CCN_WLOAD_AT0
-        constexpr bool WLOAD_AT0 = true;
-#else
-        constexpr bool WLOAD_AT0 = false;
-#endif
-        static_assert((NG * NROW) % WIN == 0 && NG % DG == 0, "static ring indexing");
+    if constexpr (NTAPS == 9) {
+        // 3x3, column-per-wave form: wave w owns ALL TH tile rows of the 32 output channels nt*128 + 32w, on
+        // v_mfma_f32_16x16x32_bf16 (round 3; rounds 1-2 ran v_mfma_f32_32x32x16_bf16 here).  The chip holds a higher clock on this
+        // shape: the same loop on random operands, same LDS and weight bytes, 1.90 vs 1.65 GHz = +12.5 % by wall at 3 % more cycles
+        // (tools/ubench/consumer_loop.hip shape_ab, profiles/r03_power_ubench.txt; MI355X_MICROARCH.md DVFS give-back item 7).
+        //   * wave tile = pixel halves p x channel halves c: quarter q = 2p + c of the row's 16-register accumulator tuple (one
+        //     tuple per output row: 32 separate 4-register tuples make the allocator rotate them over the chunk loop's back edge);
+        //     operands swapped (weights = A): a lane's quarter is pixel 16p + (lane & 15), channels 16c + 4(lane >> 4) + 0..3;
+        //   * one group = (dx, 32-channel K slice k32): 6 weight fragments (dy x c) + 2 HROWS row fragments (halo row x p), each row
+        //     fragment read ONCE from LDS and used for up to six MFMAs (three output rows x both channel halves) when it arrives;
+        //   * the MFMA's k-block (lane >> 4) of slice k32 is the chunk's 16-byte channel slice s = ((g & 1) << 2 | k32 << 1 | g >> 1)
+        //     (pr3_slice, ccn_internal.h; the host / device packers put the weights in the same order) and dump() swizzles the
+        //     slices of halo column hx by (hx >> 1) & 3: with that pairing every ds_read_b128 of the loop is bank-conflict free
+        //     (its 16-lane groups mix k-blocks {0,1} or {2,3}, whose slices differ in bit 2, which the swizzle never touches);
+        //   * weights through a register ring of two groups: the six fragments of group g+1 leave in six six-MFMA steps of group g
+        //     (one 1-KiB load per step, ~1500 cycles ahead of use), wrapping into the next chunk / tile.
+        constexpr int NROW = HROWS, NSG = 2 * NROW;                // steps of a group: (halo row, pixel half)
+        constexpr int NG = 6;                                      // groups of a chunk: (dx, k32)
+        constexpr int WIN = 6, PF = 4;                             // row-fragment window / prefetch distance (steps of <= 96 cycles)
+        static_assert((NG * NSG) % WIN == 0, "static window indexing");
         f32x16 acc[TH];
         const int n32 = a.Cout_pad / 32;
         constexpr unsigned COLB = 36 * 1024;
@@ -703,20 +645,18 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             const int nt = tile - CCN_FDIV(tile, a.fd_nt, a.n_nt) * a.n_nt;
             return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(chunk * n32 + nt * 4 + wave) * COLB));
         };
-        auto rbase = [&](int row_lin, int hx) __attribute__((always_inline)) { return row_lin * 128 + (((hx >> 1) & 6) << 4) + (((h ^ (hx >> 1)) & 1) << 4); };
-        int b16x[3];                                               // halo row 0, column r + dx (dx = 0..2 <-> -1..+1), k-slice 0
+        const int px16 = lane & 15, g4 = lane >> 4;
+        int b16x[3];                                               // halo row 0, column px16 + dx (dx = 0..2 <-> -1..+1), pixel half 0, k32 = 0
 #pragma unroll
-        for (int d = 0; d < 3; ++d) b16x[d] = rbase(r + d, r + d);
-        u32x4 bq[DG][3];
+        for (int d = 0; d < 3; ++d) { const int hx = px16 + d; b16x[d] = hx * 128 + ((((g4 & 1) << 2) | ((g4 >> 1) ^ ((hx >> 1) & 3))) << 4); }
+        u32x4 bq[2][3][2];
         {
             const unsigned wb = wbase_of(vt_tile(vt(0)), vt_kh(vt(0)) * nck);
 #pragma unroll
-            for (int g = 0; g < DG - 1; ++g)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) bq[g][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, wb + (g * 3 + dy) * 1024, 0);
+            for (int f = 0; f < 6; ++f) bq[0][f >> 1][f & 1] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, wb + f * 1024, 0);
         }
-        // staging address of this lane: pixel i*32 + r, channels 32*wave + g*8 + 4*h .. +3
-        const int stg_lane = r * L::SP + (wave * 32 + 4 * h) * 2;
+        // staging address of this lane: pixel i*32 + 16p + px16, channels 32*wave + 16c + 4*g4 .. +3
+        const int stg_lane = px16 * L::SP + (wave * 32 + 4 * g4) * 2;
         if constexpr (HSPLIT < HROWS) {
             request_first(HSPLIT, HROWS, false);                   // the consumers' share of the first chunk (they are idle until it is staged)
             if (CCN_STAMPS_PTR(a)) {                               // diagnostics: the cold start in three parts [100 MHz ticks since this wave's start]
@@ -734,12 +674,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         // Cout not a multiple of 128 (C4's 192-wide level): the last N tile is part padding.  Every tile of a workgroup has the same N
         // tile when the grid is a multiple of n_nt (tiles are visited with stride `grid`), so a consumer wave whose 32 channels are ALL
         // padding has nothing to compute in this launch: it only keeps the barrier protocol (the epilogue masks those channels anyway).
-#ifdef CCN_AB_NO_IDLE_PAD
-        const bool idle_w = false;
-#else
         const bool idle_w = ks == 1 && grid % a.n_nt == 0 &&
                             (vt_tile(vt(0)) - CCN_FDIV(vt_tile(vt(0)), a.fd_nt, a.n_nt) * a.n_nt) * BN + wave * 32 >= a.Cout;
-#endif
         if (idle_w) { for (int kk = 0; kk < ktotal; ++kk) timed_barrier(); }
         else
         for (int ti = 0; ti < my_tiles; ++ti) {
@@ -755,51 +691,43 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 int bufoff = (k & 1) * L::A_BYTES; asm volatile("" : "+v"(bufoff));
                 u32x4 rw[WIN];
                 int ag = 0;
-                // row fragment `s` of the chunk's stream (group s / 10, halo row s % 10)
+                // row fragment `s` of the chunk's stream: group s / NSG = (dx, k32), halo row (s % NSG) / 2, pixel half s & 1; the
+                // row / half offset is the ds_read's immediate
                 auto rload = [&](int s_) __attribute__((always_inline)) {
-                    const int g = s_ / NROW, hh = s_ % NROW;
-                    if (hh == 0) ag = (bufoff + b16x[g / 4]) ^ ((g & 3) << 5);
-                    rw[s_ % WIN] = *(const u32x4*)(smem + ag + hh * HPITCH * 128);
+                    const int g = s_ / NSG, hp = s_ % NSG;
+                    if (hp == 0) ag = (bufoff + b16x[g >> 1]) ^ ((g & 1) << 5);
+                    rw[s_ % WIN] = *(const u32x4*)(smem + ag + ((hp >> 1) * HPITCH + (hp & 1) * 16) * 128);
                 };
                 if (!CCN_DBG_BIT(a, 64)) {
 #pragma unroll
                 for (int s_ = 0; s_ < PF; ++s_) rload(s_);
 #pragma unroll
-                for (int s_ = 0; s_ < NG * NROW; ++s_) {
-                    const int g = s_ / NROW, hh = s_ % NROW;
+                for (int s_ = 0; s_ < NG * NSG; ++s_) {
+                    const int g = s_ / NSG, hh = (s_ % NSG) >> 1, p = s_ & 1;
                     __builtin_amdgcn_sched_barrier(0);
-                    {
-                        // refill the ring slot group g-1 released with the fragments of group g+DG-1 (wraps into the next chunk / tile).
-                        // One 1-KiB load per step, in the steps that carry three MFMAs (all four consumer waves reach the same step
-                        // together; three loads in the one-MFMA step hh = 0 was the round-1 placement, -DCCN_WLOAD_AT0=1).  Alone this
-                        // loop runs at 99.6 % of the MFMA rate (tools/ubench/consumer_loop.hip); next to the producers the loads
-                        // share the CU's vector-memory pipe with their traffic (finding 10).
-                        const int pg = g + DG - 1;
-#ifdef CCN_AB_WHOT
-                        const unsigned off = wb_cur;                   // timing experiment (wrong results): every group re-reads the same 3 KiB -> L1 hits
-#else
-                        const unsigned off = pg < NG ? wb_cur + (unsigned)(pg * 3) * 1024u : wb_nxt + (unsigned)((pg - NG) * 3) * 1024u;
-#endif
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int lh = WLOAD_AT0 ? 0 : (TH == 8 ? 2 + 2 * dy : 2 + dy);
-                            if (hh == lh) bq[pg % DG][dy] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off + dy * 1024, 0);
-                        }
+                    // fragment f of group g+1 (wraps into the next chunk / tile) leaves in the f-th six-MFMA step of this group
+                    const bool wl = TH == 8 ? (p == 0 && hh >= 2 && hh <= 7) : (hh >= 1 && hh <= 3);
+                    if (wl) {
+                        const int f = TH == 8 ? hh - 2 : (hh - 1) * 2 + p;
+                        const unsigned off = g + 1 < NG ? wb_cur + (unsigned)((g + 1) * 6 + f) * 1024u : wb_nxt + (unsigned)f * 1024u;
+                        bq[(g + 1) & 1][f >> 1][f & 1] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, off, 0);
                     }
-                    if (s_ + PF < NG * NROW) rload(s_ + PF);
+                    if (s_ + PF < NG * NSG) rload(s_ + PF);
                     int nm = 0;
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int i = hh - dy;
-                        if (i >= 0 && i < TH) { mfma16<T>(acc[i], bq[g % DG][dy], rw[s_ % WIN]); ++nm; }
+                        if (i >= 0 && i < TH) {
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) { mfma16q(acc[i], p * 2 + c, bq[g & 1][dy][c], rw[s_ % WIN]); ++nm; }
+                        }
                     }
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
+                    for (int m = 0; m < 6; ++m) {
                         if (m < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (WLOAD_AT0 ? hh == 0 : (m == 1 && (TH == 8 ? (hh == 2 || hh == 4 || hh == 6) : (hh >= 2 && hh <= 4))))
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        if (m == 2 && wl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (m & 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -809,27 +737,21 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
                     for (int i = 0; i < TH; ++i)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
+                        for (int q = 0; q < 4; ++q) {
                             const f32x16& c = acc[i];
                             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            const u32x2 pk = {pack_bf2(c[g * 4], c[g * 4 + 1]), pack_bf2(c[g * 4 + 2], c[g * 4 + 3])};
-                            *(u32x2*)(stg + stg_lane + i * 32 * L::SP + (g * 8) * 2) = pk;
+                            const u32x2 pk = {pack_bf2(c[q * 4], c[q * 4 + 1]), pack_bf2(c[q * 4 + 2], c[q * 4 + 3])};
+                            *(u32x2*)(stg + stg_lane + (i * 32 + (q >> 1) * 16) * L::SP + ((q & 1) * 16) * 2) = pk;
                         }
                 }
                 timed_barrier();                                   // chunk k+1 visible, chunk k released, staging complete
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (coop_tail) {
-            epi_setup(vt(my_tiles - 1));
-            epi_request(NQ / 2, NQ);
-            epilogue(NQ / 2, NQ);
-            if (a.part) raw_barrier();                             // the producers combine all eight waves' sums behind it
-        }
         stamp(2); stamp_cycles();
-        return;
-    }
-    static_assert(NTAPS == 9 || TH == 8, "the 4x2 fragment form works on 8-row tiles");
+    } else {
+    // ConvTranspose parities (4 taps) and stride-2 plane passes (2 taps): 2 x 2 waves of 4 x 2 fragments of v_mfma_f32_32x32x16_bf16
+    static_assert(TH == 8, "the 4x2 fragment form works on 8-row tiles");
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[MF][NF];
     // byte offset of this lane's 16-byte slice (k-slice 0) of halo pixel (row_lin = hy*HPITCH + hx): slice index h ^ (hx >> 1)
@@ -838,10 +760,6 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     int prow[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) prow[i] = ((wm * MF + i) + 1) * HPITCH + r + 1;
-    // 3x3: per dx the swizzle term of column r + 1 + dx plus the dx pixel step, relative to the (dy = -1) row
-    int b16x[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) b16x[d] = rbase(d - 1 - HPITCH, r + d);
     // weight fragments: [chunk][Cout_pad/32][tap][kk][lane] x 16 B (host-packed); this wave owns columns nt*4 + wn*2 + {0,1}
     const int n32 = a.Cout_pad / 32;
     constexpr unsigned COLB = NSTEP * 1024;                        // bytes of one 32-channel column of one chunk
@@ -874,7 +792,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int v = vt(ti), v_next = ti + 1 < my_tiles ? vt(ti + 1) : v;
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
-        int toffs[NTAPS == 9 ? 1 : NTAPS], tdxs[NTAPS == 9 ? 1 : NTAPS];   // ConvTranspose: the parity's 2x2 taps (wave-uniform)
+        int toffs[NTAPS], tdxs[NTAPS];                            // ConvTranspose: the parity's 2x2 taps (wave-uniform)
         if constexpr (NTAPS == 4) {
             const int par = CCN_FDIV(tile, a.fd_nt, a.n_nt) % NPARC;
 #pragma unroll
@@ -899,32 +817,16 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
 #pragma unroll
             for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop
             u32x4 av[2][MF];
-            int abase[MF], akk[MF];
-            // 3x3: steps run in (dx, kk, dy) order -- the address of (row i, dx, kk) serves the three dy taps through the
-            // ds_read immediate offset (dy * HPITCH * 128): 48 address VALU ops per chunk instead of 430, on a SIMD whose VALU
-            // issue is shared with a producer wave.  Other tap sets: (tap, kk) order, one address set per tap.
+            int abase[MF];
+            // steps in (tap, kk) order, one address set per tap
             auto frag = [&](int j, u32x4* av_) __attribute__((always_inline)) {
-                if constexpr (NTAPS == 9) {
-                    const int dxi = j / 12, kk = (j / 3) & 3, dyi = j % 3;
-                    if (j % 12 == 0) {
+                const int tt = j >> 2, kk = j & 3;
+                if (kk == 0) {
 #pragma unroll
-                        for (int i = 0; i < MF; ++i) abase[i] = bufoff + prow[i] * 128 + b16x[dxi];
-                    }
-                    if (j % 3 == 0) {
-#pragma unroll
-                        for (int i = 0; i < MF; ++i) akk[i] = abase[i] ^ (kk << 5);
-                    }
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + akk[i] + dyi * HPITCH * 128);
-                } else {
-                    const int tt = j >> 2, kk = j & 3;
-                    if (kk == 0) {
-#pragma unroll
-                        for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toffs[NTAPS == 9 ? 0 : tt], r + 1 + tdxs[NTAPS == 9 ? 0 : tt]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
+                    for (int i = 0; i < MF; ++i) abase[i] = bufoff + rbase(prow[i] + toffs[tt], r + 1 + tdxs[tt]);
                 }
+#pragma unroll
+                for (int i = 0; i < MF; ++i) av_[i] = *(const u32x4*)(smem + (abase[i] ^ (kk << 5)));
             };
             if (!CCN_DBG_BIT(a, 64)) {                                   // CCN_DBG=64: consumers idle (timing experiments only)
             frag(0, av[0]);
@@ -975,23 +877,15 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (coop_tail) {
-        epi_setup(vt(my_tiles - 1));
-        epi_request(NQ / 2, NQ);
-        epilogue(NQ / 2, NQ);
-        if (a.part) raw_barrier();
-    }
     stamp(2); stamp_cycles();
+    }
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-#ifndef PR_D
-#define PR_D 6
-#endif
+constexpr int PR_D = 6;                                          // weight ring depth (steps) of the 4-tap / 2-tap forms
 typedef void (*pr_fn_t)(const ConvArgs, int);
 static pr_fn_t pick_pr(int ntaps, int mode, int th = 8, int gs = 0)
 {
-#ifndef CCN_AB_RUNTIME_GS
     if (gs == 1 && ntaps == 9 && mode != 2) {
         if (th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4, 1>;
         return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 8, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 8, 1>;
@@ -1000,7 +894,6 @@ static pr_fn_t pick_pr(int ntaps, int mode, int th = 8, int gs = 0)
         if (th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4, 2> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 4, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4, 2>);
         return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 8, 2> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 8, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 8, 2>);
     }
-#endif
     if (ntaps == 9 && th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2, 4> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4>);
     if (ntaps == 9) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 2> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0>);
     if (ntaps == 2) return mode == 1 ? (pr_fn_t)conv_pr_kernel<2, 8, 1> : (mode == 2 ? (pr_fn_t)conv_pr_kernel<2, 8, 2> : (pr_fn_t)conv_pr_kernel<2, 8, 0>);
@@ -1086,12 +979,8 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     }
     // Producer waves outrank the consumers on the 2-chunk 3x3 layers (the 128-channel levels, where the producers are the pole and
     // the consumers wait a quarter of their time at barriers): +0.8 % on two boxes in product builds; on every layer: -0.5..+1.7 %
-    // by box; on the deep-K layers only: 0.  (-DCCN_AB_PF_NONE: consumers first everywhere, the round-1 setting.)
-#if defined(CCN_AB_PF_NONE)
-    d.prod_first = 0;
-#else
+    // by box; on the deep-K layers only: 0.
     d.prod_first = (a.nchunk <= 2 && c3) ? 1 : 0;
-#endif
     static const char* env = diag_env("CCN_STAMPS");
     if (env && (unsigned)atoi(env) == (unsigned)ntiles && (!strchr(env, ':') || atoi(strchr(env, ':') + 1) == a.ntaps)) {   // CCN_STAMPS=<tiles>[:<ntaps>]
         if (!g_stamps) { if (hipMalloc((void**)&g_stamps, (size_t)1024 * 24 * 8) != hipSuccess) return hipErrorOutOfMemory; }

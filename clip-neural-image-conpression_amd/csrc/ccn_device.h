@@ -58,6 +58,14 @@ template <> __device__ __forceinline__ void mfma16<__bf16>(f32x16& acc, const u3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16 on quarter q (registers 4q .. 4q+3) of a 16-register accumulator tuple
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16q(f32x16& acc, const int q, const u32x4& a, const u32x4& b) {
+    f32x4q t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), t, 0, 0, 0);
+    acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3];
+}
+
 
 // ---- GroupNorm-apply (+ SiLU) on one 16-byte chunk while staging the A operand ----------------------------
 // fp32 (parity mode): y = fma(x, a, c); silu(y) = y / (1 + expf(-y)) with full-precision expf and a true division.

@@ -24,6 +24,23 @@ namespace ccn { inline const char* diag_env(const char*) { return nullptr; } }
 
 namespace ccn {
 
+// ---- weight fragment order of the persistent kernel's 3x3 stride-1 form (ccn_conv_pr.hip, v_mfma_f32_16x16x32_bf16) --------
+// Per 64-channel Cin chunk and 32-channel Cout column: 36 fragments of 1 KiB (64 lanes x 8 bf16) in the order the consumer wave
+// uses them: f = ((dx * 2 + k32) * 3 + dy) * 2 + c, with k32 the 32-channel K slice and c the 16-channel half of the column.  Lane
+// l of a fragment holds output channel 16c + (l & 15) and the eight input channels of the chunk's 16-byte slice
+// pr3_slice(l >> 4, k32); the consumers read the same slice of the staged input for that lane group.
+// Element (output channel n, input channel k, tap t = dy * 3 + dx) of a layer with Np padded output channels lands at:
+__host__ __device__ inline int pr3_slice(int g, int k32) { return ((g & 1) << 2) | (k32 << 1) | (g >> 1); }
+__host__ __device__ inline size_t pr3_frag_index(int n, int k, int t, int Np)
+{
+    const int chunk = k >> 6, s = (k & 63) >> 3, e = k & 7;
+    const int g = ((s >> 2) & 1) | ((s & 1) << 1), k32 = (s >> 1) & 1;           // inverse of pr3_slice
+    const int nn = n >> 5, c = (n >> 4) & 1, lane = g * 16 + (n & 15);
+    const int dy = t / 3, dx = t - dy * 3;
+    const int f = ((dx * 2 + k32) * 3 + dy) * 2 + c;
+    return ((((size_t)chunk * (size_t)(Np >> 5) + nn) * 36 + f) * 64 + lane) * 8 + e;
+}
+
 // ---- implicit-GEMM convolution ------------------------------------------------------------------
 // One kernel family covers every contraction on the path (models/unet.py:55,63,75,79 and
 // models/blocks.py:34,36).  M-space = the pixel grid a block tiles (TH=4 x TW=32 pixels per block):
@@ -36,8 +53,8 @@ enum ConvKind { KIND_C3S1 = 0, KIND_C3S2 = 1, KIND_CT4 = 2, KIND_STEM = 3, KIND_
 struct ConvArgs {
     const void* in;         // NHWC T [B][Hin][Win][Cin]   (stem: NCHW fp32 [B][Cin][Hin][Win])
     const void* w;          // packed [tap][Cout_pad][Cin_pad] T
-    const void* wfrag;      // 3x3 s1 layers with Cout_pad % 128 == 0: the same weights in MFMA fragment order
-                            // [Cin chunk][Cout_pad/32][tap][kk 0..3][lane 0..63] x 16 B (ccn_conv_pr.hip), else null
+    const void* wfrag;      // layers with Cout_pad % 128 == 0 (bf16 mode): the same weights in MFMA fragment order for ccn_conv_pr.hip
+                            // (3x3 s1: pr3_frag_index above; ConvTranspose / stride 2: see pack_convT / pack_conv3), else null
     const float* bias;      // [Cout]
     void* out;              // NHWC T [B][Hout][Wout][Cout] (head: unused)
     const float2* gn_ab;    // prologue GroupNorm: per sample C float2 slots, pair-interleaved {scale(2p), scale(2p+1), shift(2p), shift(2p+1)}, or null

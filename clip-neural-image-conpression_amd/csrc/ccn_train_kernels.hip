@@ -114,14 +114,9 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
                 break;
         }
         if (d.mode == PK_FRAG3 || d.mode == PK_FRAG3_DG) {
-            // [Cin chunk of 64][N/32][step j = dx*12 + kk*3 + dy][lane = h*32 + r][8]: lane (r, h) of column block nn holds output channel
-            // nn*32 + r and input channels chunk*64 + (2 kk + h)*8 + e (pack_conv3 in ccn_api.hip)
-            const int c = k >> 6, kk2 = (k & 63) >> 3, e = k & 7, nn = n >> 5, lane = (kk2 & 1) * 32 + (n & 31), n32 = Np >> 5;
+            // fragment order of the persistent kernel's 3x3 form (pr3_frag_index, ccn_internal.h; pack_conv3 in ccn_api.hip)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int j = (t % 3) * 12 + (kk2 >> 1) * 3 + t / 3;
-                dst[((((size_t)c * n32 + nn) * 36 + j) * 64 + lane) * 8 + e] = to_elem<T>(v[t]);
-            }
+            for (int t = 0; t < 9; ++t) dst[pr3_frag_index(n, k, t, Np)] = to_elem<T>(v[t]);
             continue;
         }
 #pragma unroll

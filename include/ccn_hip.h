@@ -69,6 +69,15 @@ int ccn_param_info(ccn_handle_t h, int32_t i, const char** name, int64_t shape[4
  * (out,in)); host or device pointer.  The library copies; the caller keeps ownership. */
 int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 
+/* How CCN_DTYPE_BF16 rounds the conv weights to bf16 when they are repacked (call before ccn_commit_params; no effect in fp32
+ * mode).  CCN_ROUND_DIFFUSED (default): sequential error diffusion along (cin, ky, kx) of every output channel -- partial sums
+ * of the weights track the fp32 checkpoint, which keeps the 50-step reconstructions within north_star's 0.1 % PSNR gate of the
+ * fp32 reference path (eval/metrics.py:22-29; measured 0.075 % max against 0.165 % with independent rounding) at no run-time
+ * cost.  CCN_ROUND_NEAREST: independent round-to-nearest-even, what `.to(torch.bfloat16)` of the checkpoint gives. */
+#define CCN_ROUND_NEAREST  0
+#define CCN_ROUND_DIFFUSED 1
+int ccn_set_weight_rounding(ccn_handle_t h, int32_t mode);
+
 /* strict=True check (every key loaded exactly once with the right shape), then repack to the kernel
  * layouts ([tap][Cout][Cin], bf16 copies in bf16 mode) and upload.  Synchronises the device. */
 int ccn_commit_params(ccn_handle_t h);

@@ -405,15 +405,16 @@ def test_c2_architecture_odd_shapes(synth, c2_sd, B, H, W):
 def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
     """The exact bench.py workload (C2: batch 8, 256 px, 50 steps, bf16, fused graph on the persistent kernel) against
     (a) the reference's device='cpu' run of record 0 (golden), (b) this library's fp32 parity mode on all 8 rows, and
-    (c) PSNR against the synthetic originals in both modes -- north_star asks for PSNR within 0.1 %.
-    Measured on MI355X (round 2; the same numbers are printed in bench.py's `parity` block on every run):
+    (c) PSNR against the synthetic originals in both modes -- north_star asks for PSNR within 0.1 % (eval/metrics.py:22-29).
+    Measured on MI355X (the same numbers are printed in bench.py's `parity` block on every run):
       fp32 mode row 0 vs reference: max-abs 2.9e-4 (gate 1e-3: met);
       bf16 row 0 vs reference: max-abs 0.21, mean-abs 0.032; bf16 vs fp32 mode, all rows: max-abs 0.32, mean-abs 0.032
       (the reference's own bf16-autocast run deviates 0.30 / 0.037 from its fp32 run on these weights);
-      PSNR: 11.353 dB (fp32 mode) vs 11.366 dB (bf16): per-record relative delta 0.11 % mean, 0.17 % max against the
-      full-precision weights -- above the 0.1 % gate; fp32 mode meets it.  The cause is the bf16 rounding of the weights, not
-      the arithmetic (see the end of this test, where the gate is asserted against fp32 arithmetic on the rounded weights).
-    Bounds asserted: 2x the measured deviations."""
+      PSNR, per-record relative delta of bf16 mode against the fp32 mode ON THE FULL-PRECISION WEIGHTS: round 2 (conv weights
+      rounded to bf16 independently, round-to-nearest-even) 0.11 % mean / 0.165 % max -- above the gate; round 3 (error-diffused
+      rounding in ccn_commit_params, tools/weight_rounding_probe.py) 0.044 % mean / 0.075 % max -- the gate is asserted as stated.
+      With weight_rounding="nearest" the old shift is reproduced (asserted below: the diffusion is what closes it).
+    Other bounds asserted: 2x the measured deviations."""
     from clip_feature_codec.eval.metrics import psnr
     g = golden("c2_sample.npz")
     B, S, T = 8, 256, 50
@@ -436,17 +437,15 @@ def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
           f"bf16 vs fp32 all rows max {float(dall.max()):.3f} mean {float(dall.mean()):.4f}; "
           f"PSNR fp32 {p32.mean():.4f} dB bf16 {p16.mean():.4f} dB, rel delta mean {rel.mean():.2e} max {rel.max():.2e} "
           f"(0.1 % gate {'met' if rel.max() <= 1e-3 else 'NOT met'} by bf16 mode)")
-    assert rel.max() < 3.5e-3, rel                              # 2x the measured 0.17 %
-    # Where that shift comes from (tools/bf16_bias_probe.py): NOT from the bf16 arithmetic -- zero-mean eps noise of twice its size
-    # moves the fp32 mode's PSNR by < 0.003 % -- but from rounding the conv WEIGHTS to bf16, a static change of the model that any
-    # bf16 implementation (the reference's autocast included) shares: fp32 arithmetic on the bf16-rounded weights scores 11.3653 dB,
-    # bf16 mode 11.3657 dB.  Against that reference the 0.1 % gate is asserted:
-    sd_r = {k: (torch.from_numpy(v).to(torch.bfloat16).float().numpy() if v.ndim == 4 else v) for k, v in c2_sd.items()}
-    x32r = sampler.sample(make_net(sd_r, 128, (1, 2, 2)), z, (B, 3, S, S), steps=T, x_T=xT).clamp(-1, 1).cpu().numpy()
-    p32r = np.array([psnr(orig[k], x32r[k]) for k in range(B)])
-    relr = np.abs(p16 - p32r) / np.abs(p32r)
-    print(f"  vs fp32 arithmetic on bf16-rounded weights: PSNR {p32r.mean():.4f} dB, rel delta mean {relr.mean():.2e} max {relr.max():.2e}")
-    assert relr.max() <= 1e-3, relr                             # north_star's 0.1 % PSNR gate, measured 0.004-0.02 %
+    assert rel.max() <= 1e-3, rel                               # north_star's 0.1 % PSNR gate, bf16 mode vs fp32 mode on the fp32 weights
+    # the same kernels on independently rounded weights: the shift the diffusion removes (measured 0.165 % max)
+    net16n = CLIPCondUNet(z_dim=512, base=128, ch_mult=(1, 2, 2), dtype="bf16", weight_rounding="nearest").to(DEV).eval()
+    net16n.load_state_dict({k: torch.from_numpy(v) for k, v in c2_sd.items()}, strict=True)
+    x16n = sampler.sample(net16n, z, (B, 3, S, S), steps=T, x_T=xT).clamp(-1, 1).cpu().numpy()
+    p16n = np.array([psnr(orig[k], x16n[k]) for k in range(B)])
+    reln = np.abs(p16n - p32) / np.abs(p32)
+    print(f"  weight_rounding='nearest': PSNR {p16n.mean():.4f} dB, rel delta mean {reln.mean():.2e} max {reln.max():.2e}")
+    assert reln.mean() > 1.5 * rel.mean(), (reln.mean(), rel.mean())
     # fp32 mode vs the reference on record 0: PSNR within 0.1 % follows from max-abs < 1e-3 (uint8 truncation moves few pixels)
     torch.cuda.synchronize()
     net16.native().poll_errors()                                # no device-side failure (split-K hand-off timeout) was flagged

@@ -13,10 +13,12 @@ from clip_feature_codec.diffusion.ddim import DDIMSampler
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--steps", type=int, default=2); ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=256); ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--base", type=int, default=128); ap.add_argument("--ch-mult", default="1,2,2")    # C4: --size 512 --base 192 --ch-mult 1,2,2,4 --batch 4
 a = ap.parse_args()
 dev = "cuda:0"
-sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
-net = CLIPCondUNet(512, 128, (1, 2, 2), dtype=a.dtype).to(dev).eval()
+cm = tuple(int(v) for v in a.ch_mult.split(","))
+sd = synth.synth_state_dict(synth.unet_param_spec(512, a.base, cm))
+net = CLIPCondUNet(512, a.base, cm, dtype=a.dtype).to(dev).eval()
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 z = torch.from_numpy(synth.synth_z(a.batch)).to(dev)
 xT = torch.from_numpy(synth.start_noise(range(a.batch), a.size, 100)).to(dev)

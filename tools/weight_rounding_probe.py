@@ -61,6 +61,15 @@ def bf16_diffused(w, transposed):
     return np.ascontiguousarray(np.moveaxis(o, 0, 1)) if transposed else o
 
 
+def bf16_diffused_tapmajor(w, transposed):
+    """The same diffusion walking (ky, kx, cin) with cin fastest: channel sums of one tap first, taps last."""
+    a = np.moveaxis(w, 1, 0) if transposed else w
+    a2 = np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))          # (co, ky, kx, ci)
+    o = bf16_diffused(a2.reshape(a2.shape[0], 1, 1, -1), False).reshape(a2.shape)
+    o = np.ascontiguousarray(np.transpose(o, (0, 3, 1, 2)))
+    return np.ascontiguousarray(np.moveaxis(o, 0, 1)) if transposed else o
+
+
 def level_of(k):
     if k.startswith("in_conv"): return "stem"
     if k.startswith("out."): return "head"
@@ -114,6 +123,19 @@ report("bf16, error diffused per output channel (cin, ky, kx)", {**sd, **dif})
 print("--- bf16 MODE (bf16 storage + bf16 MFMA) on the same weights")
 report("bf16 mode, fp32 checkpoint (RNE in ccn_commit_params)", sd, "bf16")
 report("bf16 mode, checkpoint pre-rounded with error diffusion", {**sd, **dif}, "bf16")
+print("--- under error diffusion: which levels still carry the shift (fp32 arithmetic; this level kept fp32 / stored as fp16)")
+levels = []
+for k in conv_keys:
+    if level_of(k) not in levels: levels.append(level_of(k))
+for lv in levels:
+    ks = [k for k in conv_keys if level_of(k) == lv]
+    report(f"diffused bf16, but {lv} kept fp32", {**sd, **dif, **{k: sd[k] for k in ks}})
+hot = [k for k in conv_keys if level_of(k) in ("stem", "down 128ch 256^2 res")]
+report("diffused bf16, stem + 256^2 res convs as fp16", {**sd, **dif, **{k: fp16_rne(sd[k]) for k in hot}})
+hot2 = hot + [k for k in conv_keys if level_of(k) in ("down 128ch 128^2 res", "head", "up 128ch 128^2 res")]
+report("diffused bf16, stem + 256^2 + 128^2 res + head as fp16", {**sd, **dif, **{k: fp16_rne(sd[k]) for k in hot2}})
+dif_t = {k: bf16_diffused_tapmajor(sd[k], k.startswith("up.") and sd[k].shape[2] == 4) for k in conv_keys}
+report("bf16, error diffused tap-major (cin fastest)", {**sd, **dif_t})
 if not quick:
     print("--- leave-one-IN: only this level's conv weights rounded to bf16 (RNE), everything else fp32")
     levels = []
