@@ -148,7 +148,7 @@ class NativeUNet:
     MAX_WORKSPACES = 8
 
     def __init__(self, z_dim: int, base: int, ch_mult: Sequence[int], time_dim: int, img_ch: int,
-                 groups: int = 8, dtype="fp32", device="cuda", weight_rounding: str = "diffused") -> None:
+                 groups: int = 8, dtype="fp32", device="cuda", weight_rounding: str = "phases") -> None:
         self.lib = load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -161,9 +161,10 @@ class NativeUNet:
         with torch.cuda.device(self.device):
             check(self.lib.ccn_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
-        if weight_rounding not in ("nearest", "diffused"):
-            raise ValueError("weight_rounding must be 'nearest' or 'diffused'")
-        check(self.lib.ccn_set_weight_rounding(self.h, 1 if weight_rounding == "diffused" else 0))
+        modes = {"nearest": 0, "diffused": 1, "phases": 2}
+        if weight_rounding not in modes:
+            raise ValueError(f"weight_rounding must be one of {sorted(modes)}")
+        check(self.lib.ccn_set_weight_rounding(self.h, modes[weight_rounding]))
         self._ws: Dict[Tuple[int, int, int, int, int], Workspace] = {}
 
     def close(self) -> None:

@@ -27,6 +27,8 @@ from .. import _native
 class DDIMSampler:
     """Deterministic (eta = 0) / stochastic DDIM sampler."""
 
+    MAX_NOISE_BUFFERS = 4
+
     def __init__(self, scheduler, eta: float = 0.0) -> None:
         self.sch = scheduler
         self.eta = eta
@@ -47,10 +49,16 @@ class DDIMSampler:
                 return model.sample_ddim(z_clip, x, ts, coef[:, :4], use_graph=self.use_graph, slot=slot)
             # eta > 0: every noisy step's draw up front, into a buffer kept per (shape, steps, slot) so that the captured graph
             # (keyed by the buffer's address) is replayed by later calls
+            # Memory: steps x batch x C x H x W fp32 per key (314 MB at C2: 50 steps, batch 8, 256 px; 1.26 GB at C4) -- at most
+            # MAX_NOISE_BUFFERS keys are kept, least recently used first (the library bounds its captured graphs per plan likewise)
             key = (tuple(shape), steps, slot, str(device))
-            buf = self._noise.get(key)
+            buf = self._noise.pop(key, None)
             if buf is None:
-                buf = self._noise[key] = torch.empty((steps,) + tuple(shape), dtype=torch.float32, device=device)
+                while len(self._noise) >= self.MAX_NOISE_BUFFERS:
+                    torch.cuda.synchronize(device)                    # a replay on a side stream may still read the evicted draws
+                    self._noise.pop(next(iter(self._noise)))
+                buf = torch.empty((steps,) + tuple(shape), dtype=torch.float32, device=device)
+            self._noise[key] = buf                                    # (re)insert as most recently used
             for i in range(steps):
                 if float(coef[i, 4]) > 0:
                     buf[i].normal_()                                  # == torch.randn_like(x): same generator, same order

@@ -58,11 +58,12 @@ class CLIPCondUNet(nn.Module):
     """FiLM-conditioned pixel-space U-Net, epsilon prediction."""
 
     def __init__(self, z_dim: int = 512, base: int = 128, ch_mult: Tuple[int, ...] = (1, 2, 2),
-                 time_dim: int = 256, img_ch: int = 3, dtype: str = "fp32", weight_rounding: str = "diffused") -> None:
+                 time_dim: int = 256, img_ch: int = 3, dtype: str = "fp32", weight_rounding: str = "phases") -> None:
         super().__init__()
         self.arch = dict(z_dim=z_dim, base=base, ch_mult=tuple(ch_mult), time_dim=time_dim, img_ch=img_ch)
         self.compute_dtype = dtype
-        # bf16 mode only: "diffused" (error-diffused rounding of the conv weights, ccn_set_weight_rounding) or "nearest"
+        # bf16 mode only (ccn_set_weight_rounding): "phases" (error diffusion within every output channel AND along the DDIM steps),
+        # "diffused" (within the output channel only), "nearest" (independent rounding)
         self.weight_rounding = weight_rounding
         # parameter containers, registered in the reference's order (same keys, same RNG consumption)
         self.time_proj = nn.Sequential(nn.Linear(time_dim, time_dim * 4), nn.SiLU(), nn.Linear(time_dim * 4, time_dim))

@@ -112,12 +112,20 @@ class UNetFunction(torch.autograd.Function):
             fp.rebind_grads()
             if state.ddp_bucketed and state.world() > 1:
                 d = d * (1.0 / state.world())      # the sum over ranks is then already the mean
-                state.trainer.backward(fp.flat, fp.grad, x, zz, d, bucket_cb=state.enqueue_bucket)
+                # inside `with state.no_sync():` (all micro-batches but the last) the gradients only accumulate locally; the last
+                # backward's bucket all-reduces then carry the whole accumulated sum -- torch DDP's no_sync semantics.  Without
+                # it every backward would re-reduce the already averaged earlier micro-batches (x world).
+                state.trainer.backward(fp.flat, fp.grad, x, zz, d, bucket_cb=state.enqueue_bucket if state.sync_grads else None)
             else:
                 state.trainer.backward(fp.flat, fp.grad, x, zz, d)
             return (None,) * (4 + len(fp.views))
+        # foreign .grad tensors (not views of the flat gradient buffer): the gradients go back through autograd.  Under data
+        # parallelism they must still be averaged -- one blocking all-reduce of THIS backward's gradient here (also inside no_sync():
+        # what autograd accumulates into foreign .grad tensors afterwards is out of the library's reach), never a silent per-rank one.
         g = torch.zeros_like(fp.flat)
         state.trainer.backward(fp.flat, g, x, zz, d)
+        if state.ddp_bucketed and state.world() > 1:
+            average_gradients(g)
         grads = tuple(g[off:off + n].view(p.shape) for p, off, n in fp.views)
         return (None, None, None, None) + grads
 
@@ -132,7 +140,22 @@ class TrainState:
         self.fp = FlatParams(net, self.trainer)
         self.dtype = dtype
         self.ddp_bucketed = False          # UNetFunction.backward all-reduces finished gradient ranges while it still runs
+        self.sync_grads = True             # False inside no_sync(): gradient accumulation over micro-batches without communication
         self._works: list = []
+
+    def no_sync(self):
+        """Context manager for gradient accumulation under data parallelism (torch DDP's ``no_sync``): backward passes inside it
+        only accumulate into the local gradient buffer; run the LAST micro-batch's backward outside it, then ``wait_grad_sync()``."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self.sync_grads = self.sync_grads, False
+            try:
+                yield
+            finally:
+                self.sync_grads = prev
+        return ctx()
 
     @staticmethod
     def world() -> int:

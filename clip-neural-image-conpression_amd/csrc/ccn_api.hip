@@ -62,6 +62,11 @@ struct ConvW {
     void* w = nullptr;
     void* wfrag = nullptr;      // MFMA-fragment-ordered copy for the persistent 3x3 kernel (Cout_pad % 128 == 0), else null
     float* bias = nullptr;
+    // bf16 mode, CCN_ROUND_DIFFUSED_PHASES: further roundings of the same weights, used by DDIM step i as version i % nphase
+    // (version 0 = w / wfrag above); see diffuse_round_phases()
+    int nphase = 1;
+    void* w_ph[3] = {nullptr, nullptr, nullptr};
+    void* wfrag_ph[3] = {nullptr, nullptr, nullptr};
 };
 struct NormW { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
 struct ResW {
@@ -166,7 +171,8 @@ struct ccn_handle_s {
     float* head_w_f32 = nullptr;       // (img_ch, C, 3, 3) fp32 copy of out.weight for the dedicated head kernel
     int F = 0;                          // rows of the concatenated FiLM linear
     int G = 8;
-    int weight_rounding = CCN_ROUND_DIFFUSED;   // how bf16 mode rounds the conv weights in ccn_commit_params (ccn_set_weight_rounding)
+    int weight_rounding = CCN_ROUND_DIFFUSED_PHASES;   // how bf16 mode rounds the conv weights in ccn_commit_params (ccn_set_weight_rounding)
+    std::map<std::string, std::vector<float>> host_ph[3];   // versions 1..3 of the rounded conv weights until commit
     std::vector<std::unique_ptr<Plan>> plans;
     hipStream_t cap_stream = nullptr;
     unsigned* err_host = nullptr;       // pinned, device-mapped error word the kernels OR into (ConvArgs::err)
@@ -302,6 +308,37 @@ void diffuse_round_convT(std::vector<float>& w, int I, int O)                 //
                     v = r;
                 }
         }
+}
+
+// CCN_ROUND_DIFFUSED_PHASES: error diffusion ALSO ALONG THE DDIM STEPS.  A rounded weight is a static perturbation of the model:
+// the same error acts in each of the 50 evaluations of one trajectory, and because x changes slowly from step to step its effect
+// adds up coherently -- that, not the size of one forward's error, is what moved the PSNR (zero-mean noise of twice the size drawn
+// afresh every step moves it 30x less; tools/bf16_bias_probe.py).  So the sampler uses kPhases roundings W_0 .. W_{n-1} of every conv
+// weight in turn (step i takes version i % n), built with the rounding error fed forward from version to version:
+//     W_k = round( (k + 1) W - (W_0 + ... + W_{k-1}) )      (each `round` = the spatial diffusion above)
+// Every partial sum W_0 + ... + W_k stays within half a bf16 ulp of (k + 1) W: the MEAN weight over a period is accurate to
+// ulp / (2n) instead of ulp / 2, and what remains alternates in sign from step to step with period <= n steps, which the sampler
+// averages out.  Costs n copies of the bf16 weights in HBM (65 MB each at C2) and nothing at run time: each step reads one version.
+constexpr int kPhases = 4;
+void diffuse_round_phases(ccn_handle_s* h, const ParamInfo& p)
+{
+    auto& w0 = h->host.at(p.name);
+    const std::vector<float> orig = w0;
+    const bool convT = p.shape[2] == 4;
+    auto round_one = [&](std::vector<float>& w) {
+        if (convT) diffuse_round_convT(w, (int)p.shape[0], (int)p.shape[1]);
+        else diffuse_round_conv(w, (int)p.shape[0], (int)p.shape[1], (int)(p.shape[2] * p.shape[3]));
+    };
+    round_one(w0);
+    std::vector<double> sum(orig.size());
+    for (size_t i = 0; i < orig.size(); ++i) sum[i] = (double)w0[i];
+    for (int k = 1; k < kPhases; ++k) {
+        std::vector<float> wk(orig.size());
+        for (size_t i = 0; i < orig.size(); ++i) wk[i] = (float)((double)(k + 1) * (double)orig[i] - sum[i]);
+        round_one(wk);
+        for (size_t i = 0; i < orig.size(); ++i) sum[i] += (double)wk[i];
+        h->host_ph[k - 1][p.name] = std::move(wk);
+    }
 }
 
 // element (tap, o, i) of the packed [taps][Cout_pad][Cin_pad] tensor
@@ -575,9 +612,16 @@ struct PlanBuilder {
         float* film_tab = plan->film;
         const int F = film_stride;
         const int Bc = B;
+        const ConvW cwv = cw;                                 // (device pointers of every weight version)
+        const bool frag_used = a.wfrag != nullptr;
         Launch L{family, 2.0 * macs, bytes, nullptr};
         L.fn = [=](hipStream_t s, const StepCtx& c) -> hipError_t {
             ConvArgs k = *ap;                                 // read at launch time: gn() may have fused its finalize in
+            if (cwv.nphase > 1 && (c.step % cwv.nphase)) {    // DDIM step i runs on weight version i % nphase (diffuse_round_phases)
+                const int v = c.step % cwv.nphase - 1;
+                k.w = cwv.w_ph[v];
+                if (frag_used) k.wfrag = cwv.wfrag_ph[v];
+            }
             if (film_off >= 0) k.film = film_tab + (size_t)c.step * Bc * F + film_off;
             if (is_stem) k.in = c.x_in;
             if (is_head) {
@@ -923,6 +967,9 @@ int check_device_errors(ccn_handle_s* h)
     if (e & 1u)
         return fail(CCN_EHIP, "device-side hand-off timeout: a split-K partial tile never arrived; the results of the launches enqueued "
                               "since the last successful check are invalid");
+    if (e & 2u)
+        return fail(CCN_EHIP, "split-K partners ran on different XCDs (the hand-off took the agent-scope path: results are valid, but the "
+                              "placement assumption of launch_conv_pr does not hold on this device / partition mode)");
     if (e) return fail(CCN_EHIP, "device-side error word " + std::to_string(e));
     return CCN_OK;
 }
@@ -1037,7 +1084,7 @@ int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const in
 int ccn_set_weight_rounding(ccn_handle_t h, int32_t mode)
 {
     if (!h) return fail(CCN_EINVAL, "null handle");
-    if (mode != CCN_ROUND_NEAREST && mode != CCN_ROUND_DIFFUSED) return fail(CCN_EINVAL, "unknown weight rounding mode");
+    if (mode != CCN_ROUND_NEAREST && mode != CCN_ROUND_DIFFUSED && mode != CCN_ROUND_DIFFUSED_PHASES) return fail(CCN_EINVAL, "unknown weight rounding mode");
     h->weight_rounding = mode;
     return CCN_OK;
 }
@@ -1054,33 +1101,58 @@ int ccn_commit_params(ccn_handle_t h)
     h->dev_allocs.clear();
     const ccn_config_t& c = h->cfg;
     int rc;
-    if (c.dtype == CCN_DTYPE_BF16 && h->weight_rounding == CCN_ROUND_DIFFUSED) {
-        // (the head keeps fp32 weights: head_prep_kernel scales them per sample before rounding)
+    for (auto& m : h->host_ph) m.clear();
+    const bool phases = c.dtype == CCN_DTYPE_BF16 && h->weight_rounding == CCN_ROUND_DIFFUSED_PHASES;
+    if (c.dtype == CCN_DTYPE_BF16 && h->weight_rounding != CCN_ROUND_NEAREST) {
+        // (the head keeps fp32 weights: head_prep_kernel scales them per sample and splits them into bf16 hi + lo)
         for (auto& p : h->params) {
             if (p.shape.size() != 4 || p.name == "out.weight") continue;
+            if (phases) { diffuse_round_phases(h, p); continue; }
             auto& w = h->host.at(p.name);
             const bool convT = p.shape[2] == 4;                               // up.N.weight: (Cin, Cout, 4, 4)
             if (convT) diffuse_round_convT(w, (int)p.shape[0], (int)p.shape[1]);
             else diffuse_round_conv(w, (int)p.shape[0], (int)p.shape[1], (int)(p.shape[2] * p.shape[3]));
         }
     }
+    // pack version k >= 1 of a conv's weights with the packer that made version 0 (a scratch ConvW receives the device pointers)
+    auto pack_phases = [&](ConvW& cw, const std::string& name, int (*packer)(ccn_handle_s*, ConvW&, const std::string&)) -> int {
+        cw.nphase = 1;
+        if (!phases) return CCN_OK;
+        for (int k = 1; k < kPhases; ++k) {
+            std::swap(h->host.at(name + ".weight"), h->host_ph[k - 1].at(name + ".weight"));
+            ConvW t = cw;
+            const int rc = packer(h, t, name);
+            std::swap(h->host.at(name + ".weight"), h->host_ph[k - 1].at(name + ".weight"));
+            if (rc) return rc;
+            cw.w_ph[k - 1] = t.w; cw.wfrag_ph[k - 1] = t.wfrag;
+        }
+        cw.nphase = kPhases;
+        return CCN_OK;
+    };
     h->stem = ConvW(); h->stem.kind = KIND_STEM; h->stem.Cin = c.img_ch; h->stem.Cout = c.base;
     if ((rc = pack_stem(h, h->stem, "in_conv"))) return rc;
+    if ((rc = pack_phases(h->stem, "in_conv", pack_stem))) return rc;
     for (auto& r : h->res) {
         r.c1 = ConvW(); r.c1.kind = KIND_C3S1; r.c1.Cin = r.C; r.c1.Cout = r.C;
         r.c2 = r.c1;
         if ((rc = pack_conv3(h, r.c1, r.prefix + ".conv1"))) return rc;
         if ((rc = pack_conv3(h, r.c2, r.prefix + ".conv2"))) return rc;
+        if ((rc = pack_phases(r.c1, r.prefix + ".conv1", pack_conv3))) return rc;
+        if ((rc = pack_phases(r.c2, r.prefix + ".conv2", pack_conv3))) return rc;
         r.n1.C = r.n2.C = r.C;
         if ((rc = upload_f32(h, r.prefix + ".norm1.weight", &r.n1.gamma))) return rc;
         if ((rc = upload_f32(h, r.prefix + ".norm1.bias", &r.n1.beta))) return rc;
         if ((rc = upload_f32(h, r.prefix + ".norm2.weight", &r.n2.gamma))) return rc;
         if ((rc = upload_f32(h, r.prefix + ".norm2.bias", &r.n2.beta))) return rc;
     }
-    for (size_t i = 0; i < h->downs.size(); ++i)
+    for (size_t i = 0; i < h->downs.size(); ++i) {
         if ((rc = pack_conv3(h, h->downs[i], "down." + std::to_string(3 * i + 2)))) return rc;
-    for (size_t i = 0; i < h->ups.size(); ++i)
+        if ((rc = pack_phases(h->downs[i], "down." + std::to_string(3 * i + 2), pack_conv3))) return rc;
+    }
+    for (size_t i = 0; i < h->ups.size(); ++i) {
         if ((rc = pack_convT(h, h->ups[i], "up." + std::to_string(3 * i + 2)))) return rc;
+        if ((rc = pack_phases(h->ups[i], "up." + std::to_string(3 * i + 2), pack_convT))) return rc;
+    }
     h->head = ConvW(); h->head.kind = KIND_HEAD; h->head.Cin = c.base; h->head.Cout = c.img_ch;
     if ((rc = pack_conv3(h, h->head, "out"))) return rc;
     if ((rc = upload_f32(h, "out.weight", &h->head_w_f32))) return rc;
@@ -1108,6 +1180,7 @@ int ccn_commit_params(ccn_handle_t h)
     if ((rc = upload(h, fb.data(), fb.size() * 4, (void**)&h->film_b))) return rc;
     HIPCHK(hipDeviceSynchronize());
     h->host.clear();
+    for (auto& m : h->host_ph) m.clear();
     h->committed = true;
     return CCN_OK;
 }

@@ -123,6 +123,8 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // split-K launches run the MODE 2 instantiation only (launch_conv_pr): everywhere else ks folds to 1 at compile time and the
     // hand-off branches of the epilogue disappear
     const int ks = (MODE == 2 && a.ksplit == 2) ? 2 : 1;
+    // XCD this workgroup runs on: HW_REG_XCC_ID (id 20), bits [3:0] -- only the split-K hand-off uses it
+    const unsigned xcc_id = MODE == 2 ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) : 0u;
     const int nck = a.nchunk / ks;                             // chunks per virtual tile
     const int ktotal = my_tiles * nck;
     auto vt_tile = [&](int v) __attribute__((always_inline)) { return ks == 2 ? (v >> 1) : v; };
@@ -237,20 +239,29 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             // second K half: the partner's partial tile must be complete.  Thread t reads exactly what thread t of the partner
             // wrote, so one flag per producer wave is enough.  Bounded spin: a protocol bug must not hang the GPU.
             unsigned* const fl = a.kflag + (size_t)e_tile * 4 + ew;
+            unsigned seen = 0u;
             if (lane == 0) {
                 int spins = 0;
-                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+                while ((seen = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
                 // the partner never arrived (it cannot happen while both halves are co-resident, which launch_conv_pr
                 // guarantees): the tile below is then wrong -- say so in the handle's error word, which the next API call
                 // (or ccn_poll_errors) turns into CCN_EHIP, instead of falling through silently
                 if (spins >= (1 << 22) && a.err) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             }
-            // No agent-scope acquire fence here (it would invalidate the XCD's whole L2): the partner workgroup runs on the
-            // same XCD -- partners are virtual tiles 2t, 2t+1 and launch_conv_pr makes the split-K grid a multiple of 16, so
+            // No agent-scope acquire fence on the expected path (it would invalidate the XCD's whole L2): the partner workgroup runs
+            // on the same XCD -- partners are virtual tiles 2t, 2t+1 and launch_conv_pr makes the split-K grid a multiple of 16, so
             // that every XCD's contiguous range [x*grid/8, (x+1)*grid/8) starts at an even id and holds whole pairs -- its
             // stores are write-through to that L2, and this CU cannot hold stale lines of the partial tensor (L1 is
             // invalidated at kernel start and the lines are read for the first time now, with the L1-bypass bit set).
+            // That placement is an ASSUMPTION about the dispatcher (round-robin over the XCDs), so it is checked: the flag carries
+            // the partner's XCC_ID + 1; on a mismatch (a CU mask, another partition mode, a future driver) this wave takes the
+            // agent-scope acquire after all and reports bit 2 in the handle's error word (tests assert it is never set on the box).
+            seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+            if (seen != 0u && seen != xcc_id + 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0 && a.err) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             asm volatile("" ::: "memory");
         }
         const int nb = e_nt * BN + o16 * 8;
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             // (stores are write-through to the XCD's L2; waiting for their acknowledgement is the release -- an agent-scope
             // release fence would write back the whole L2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(a.kflag + (size_t)e_tile * 4 + ew, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(a.kflag + (size_t)e_tile * 4 + ew, xcc_id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.part && !first) {
 #pragma unroll

@@ -15,8 +15,10 @@
 
 namespace ccn {
 
-template <int NT>
-__global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int upw)
+// G16: GroupNorm groups of the output are multiples of 16 channels -> statistics kept per 16-channel pair of register quads (half the
+// registers); the kernel then fits three waves per SIMD, which is what hides its load -> MFMA -> LDS -> store latency chain
+template <int NT, bool G16>
+__global__ __launch_bounds__(256, (G16 || NT < 4) ? 3 : 2) void stem_kernel(const ConvArgs a, const int upw)
 {
     constexpr int TRP = NT * 64 + 16;                              // strip pitch in bytes (C bf16 + pad: conflict-free 8-byte writes)
     __shared__ __attribute__((aligned(16))) unsigned char tr[4 * 32 * TRP];
@@ -32,14 +34,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
 #pragma unroll
         for (int s = 0; s < 2; ++s) wf[j][s] = *(const u32x4*)((const unsigned char*)a.wfrag + (size_t)((j * 2 + s) * 64 + lane) * 16);
 
-    // element e (0..15) of this lane: k = 16*(e>>3) + 8h + (e&7) -> input channel c, tap (dy, dx)
-    int koff[16];
+    // element e (0..15) of this lane: k = 16*(e>>3) + 8h + (e&7) -> input channel c, tap (dy, dx).  The byte offset of (c, dy, dx)
+    // depends on the lane only through h: both variants are wave-uniform (SGPRs), the lane selects at the load (16 VGPRs less)
+    auto koff = [&](int e) __attribute__((always_inline)) -> int {
+        int o[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int k = 16 * (e >> 3) + 8 * hh + (e & 7);
+            const int c = k / 9, rem = k - c * 9, dy = rem / 3 - 1, dx = rem - (rem / 3) * 3 - 1;
+            o[hh] = __builtin_amdgcn_readfirstlane((c * HW + dy * W + dx) * 4);
+        }
+        return h ? o[1] : o[0];
+    };
     unsigned m_k = 0, m_one = 0, m_dy0 = 0, m_dy2 = 0, m_dx0 = 0, m_dx2 = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int k = 16 * (e >> 3) + 8 * h + (e & 7);
         const int c = k / 9, rem = k - c * 9, dy = rem / 3 - 1, dx = rem - (rem / 3) * 3 - 1;
-        koff[e] = (c * HW + dy * W + dx) * 4;
         if (k < K) m_k |= 1u << e;
         if (k == K) m_one |= 1u << e;
         if (dy < 0) m_dy0 |= 1u << e;
@@ -53,11 +64,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
     const unsigned out_bytes = (unsigned)((size_t)a.B * HW * C * 2);
     const auto osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
 
-    float s1[NT][4], s2[NT][4];                                     // per (n-tile, register quad): 4 consecutive channels
+    constexpr int NS = G16 ? 2 : 4;                                 // statistics slots per n-tile: quads, or pairs of quads (16 channels)
+    float s1[NT][NS], s2[NT][NS];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { s1[j][g] = 0.f; s2[j][g] = 0.f; }
+        for (int g = 0; g < NS; ++g) { s1[j][g] = 0.f; s2[j][g] = 0.f; }
 
     const int u0 = (blockIdx.x * 4 + wave) * upw;
     // software pipeline: the 16 loads of unit uu+1 are in flight while unit uu is multiplied and stored
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
         const int base = ((b * a.Cin) * HW + y * W + x) * 4;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            dst[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(isrd, (unsigned)(base + koff[e]) | (((bad >> e) & 1u) ? OOB : 0u), 0, 0));
+            dst[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(isrd, (unsigned)(base + koff(e)) | (((bad >> e) & 1u) ? OOB : 0u), 0, 0));
     };
     fetch(u0, vn);
     for (int uu = 0; uu < upw; ++uu) {
@@ -95,32 +107,32 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
                 const float lo = ((m_one >> e) & 1u) ? 1.0f : v[e], hi = ((m_one >> (e + 1)) & 1u) ? 1.0f : v[e + 1];
                 bf[s][p] = pack_bf2(lo, hi);
             }
-        f32x16 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[j][s]), __builtin_bit_cast(bf16x8, bf[s]), acc[j], 0, 0, 0);
-        }
         const bool pv = x < W;
         const float mk = pv ? 1.0f : 0.0f;
         // accumulators -> the wave's LDS strip [32 pixels][C bf16 (+16 B pad)] -> 16-byte stores, 256 contiguous bytes per pixel:
-        // direct 8-byte stores from the accumulator layout reached only 2.6 TB/s (32 scattered 16-byte pieces per instruction)
+        // direct 8-byte stores from the accumulator layout reached only 2.6 TB/s (32 scattered 16-byte pieces per instruction).
+        // One N tile at a time: its accumulator is dead once packed (a quarter of the registers of NT live accumulators).
         unsigned char* const strip = tr + wave * (32 * TRP);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[j][s]), __builtin_bit_cast(bf16x8, bf[s]), acc, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float c0 = acc[j][g * 4], c1 = acc[j][g * 4 + 1], c2 = acc[j][g * 4 + 2], c3 = acc[j][g * 4 + 3];
+                const float c0 = acc[g * 4], c1 = acc[g * 4 + 1], c2 = acc[g * 4 + 2], c3 = acc[g * 4 + 3];
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 pk = {pack_bf2(c0, c1), pack_bf2(c2, c3)};
                 *(u32x2*)(strip + r * TRP + (j * 32 + g * 8 + 4 * h) * 2) = pk;
                 const float t = (c0 + c1) + (c2 + c3);
-                s1[j][g] = fmaf(t, mk, s1[j][g]);
-                s2[j][g] = fmaf(fmaf(c0, c0, c1 * c1) + fmaf(c2, c2, c3 * c3), mk, s2[j][g]);
+                constexpr int SH = G16 ? 1 : 0;
+                s1[j][g >> SH] = fmaf(t, mk, s1[j][g >> SH]);
+                s2[j][g >> SH] = fmaf(fmaf(c0, c0, c1 * c1) + fmaf(c2, c2, c3 * c3), mk, s2[j][g >> SH]);
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // same wave: LDS is in order
         constexpr int SL = NT * 4;                                     // 16-byte slices per pixel
 #pragma unroll
@@ -139,7 +151,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float t1 = s1[j][g], t2 = s2[j][g];
+            // (G16: the pair's sum sits in its first quad's slot, the second quad's slot holds zero)
+            float t1 = G16 ? ((g & 1) ? 0.f : s1[j][g >> 1]) : s1[j][g], t2 = G16 ? ((g & 1) ? 0.f : s2[j][g >> 1]) : s2[j][g];
 #pragma unroll
             for (int s = 1; s < 32; s <<= 1) { t1 += __shfl_xor(t1, s); t2 += __shfl_xor(t2, s); }
             if (r == 0) { red[wave][j * 8 + g * 2 + h][0] = t1; red[wave][j * 8 + g * 2 + h][1] = t2; }
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvArgs a, const int u
 bool stem2_supported(int dtype, int cin, int cout, int G)
 {
     const int g = cout < G ? cout : G;
-    return dtype == 1 && cin * 9 <= 31 && (cout == 32 || cout == 64 || cout == 128) && cout % g == 0 && (cout / g) % 4 == 0;
+    return dtype == 1 && cin * 9 <= 31 && (cout == 32 || cout == 64 || cout == 128 || cout == 192) && cout % g == 0 && (cout / g) % 4 == 0;
 }
 
 // blocks per image for the chosen units-per-wave; nslot of the output's GroupNorm partials = 4 * that
@@ -177,9 +190,13 @@ hipError_t launch_stem2(const ConvArgs& a, hipStream_t s)
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks, (unsigned)a.B);
     switch (a.Cout) {
-        case 128: hipLaunchKernelGGL(stem_kernel<4>, grid, dim3(256), 0, s, a, upw); break;
-        case 64: hipLaunchKernelGGL(stem_kernel<2>, grid, dim3(256), 0, s, a, upw); break;
-        case 32: hipLaunchKernelGGL(stem_kernel<1>, grid, dim3(256), 0, s, a, upw); break;
+        case 192: hipLaunchKernelGGL((stem_kernel<6, false>), grid, dim3(256), 0, s, a, upw); break;   // (C4's width)
+        case 128:
+            if (a.cpg % 16 == 0) hipLaunchKernelGGL((stem_kernel<4, true>), grid, dim3(256), 0, s, a, upw);
+            else hipLaunchKernelGGL((stem_kernel<4, false>), grid, dim3(256), 0, s, a, upw);
+            break;
+        case 64: hipLaunchKernelGGL((stem_kernel<2, false>), grid, dim3(256), 0, s, a, upw); break;
+        case 32: hipLaunchKernelGGL((stem_kernel<1, false>), grid, dim3(256), 0, s, a, upw); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

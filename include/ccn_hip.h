@@ -70,12 +70,19 @@ int ccn_param_info(ccn_handle_t h, int32_t i, const char** name, int64_t shape[4
 int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 
 /* How CCN_DTYPE_BF16 rounds the conv weights to bf16 when they are repacked (call before ccn_commit_params; no effect in fp32
- * mode).  CCN_ROUND_DIFFUSED (default): sequential error diffusion along (cin, ky, kx) of every output channel -- partial sums
- * of the weights track the fp32 checkpoint, which keeps the 50-step reconstructions within north_star's 0.1 % PSNR gate of the
- * fp32 reference path (eval/metrics.py:22-29; measured 0.075 % max against 0.165 % with independent rounding) at no run-time
- * cost.  CCN_ROUND_NEAREST: independent round-to-nearest-even, what `.to(torch.bfloat16)` of the checkpoint gives. */
-#define CCN_ROUND_NEAREST  0
-#define CCN_ROUND_DIFFUSED 1
+ * mode).  A rounded weight is a static perturbation of the model that acts the same way in every one of the sampler's steps, and
+ * that coherent accumulation is what moves the 50-step reconstructions: independent rounding loses 0.33 % contrast, 0.165 % PSNR
+ * (max per record) against the fp32 reference path -- above north_star's 0.1 % gate (eval/metrics.py:22-29).
+ *   CCN_ROUND_NEAREST          independent round-to-nearest-even, what `.to(torch.bfloat16)` of the checkpoint gives;
+ *   CCN_ROUND_DIFFUSED         error diffusion along (cin, ky, kx) of every output channel: partial sums of an output channel's
+ *                              weights stay within half an ulp of the fp32 sums;
+ *   CCN_ROUND_DIFFUSED_PHASES  (default) the same, plus error diffusion ALONG THE DDIM STEPS: four such roundings of every weight
+ *                              whose running sums track the fp32 weight, step i of ccn_sample uses version i % 4 (ccn_forward:
+ *                              version 0).  The mean weight over a period is accurate to 1/8 ulp; costs 4 copies of the bf16
+ *                              weights in HBM and nothing at run time. */
+#define CCN_ROUND_NEAREST         0
+#define CCN_ROUND_DIFFUSED        1
+#define CCN_ROUND_DIFFUSED_PHASES 2
 int ccn_set_weight_rounding(ccn_handle_t h, int32_t mode);
 
 /* strict=True check (every key loaded exactly once with the right shape), then repack to the kernel

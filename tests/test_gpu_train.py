@@ -461,6 +461,58 @@ def test_two_rank_bucketed_allreduce_gives_the_full_batch_gradient(tmp_path):
     assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max(), np.abs(g1 - g2).max() / np.abs(g1).max()
 
 
+def _ddp_accum_rank(rank, world, port, out, foreign):
+    """Autograd route (UNetFunction.backward) under data parallelism with two micro-batches per rank: the first inside no_sync()."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 32, (1, 2)))
+    net = make_net(sd, 32, (1, 2)).train()
+    st = net.train_state()
+    st.ddp_bucketed = world > 1
+    gen = torch.Generator("cpu").manual_seed(77)
+    B, S = 4, 32
+    x = torch.randn((B, 3, S, S), generator=gen); noise = torch.randn((B, 3, S, S), generator=gen)
+    z = torch.from_numpy(synth.synth_z(B)); t = torch.tensor([5, 250, 600, 990])
+    per = B // world
+    mine = [v[rank * per:(rank + 1) * per].to(DEV) for v in (x, z, t, noise)]
+    half = per // 2
+    if foreign:                                    # .grad tensors that are NOT views of the flat buffer: the fallback route
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+    def mb(lo, hi):
+        xx, zz, tt, nn_ = (v[lo:hi] for v in mine)
+        # mean over the GLOBAL batch: every micro-batch contributes sum / B (the 1/world factor is the library's)
+        return ((net(xx, zz, tt) - nn_) ** 2).sum() * (world / (B * 3 * xx.shape[2] * xx.shape[3]))
+    with st.no_sync():
+        mb(0, half).backward()
+    mb(half, per).backward()
+    st.wait_grad_sync()
+    torch.cuda.synchronize()
+    g = torch.cat([p.grad.flatten() for p in net.parameters()])
+    if rank == 0:
+        np.save(out, g.cpu().numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("foreign", [False, True])
+def test_two_rank_micro_batches_with_no_sync_give_the_full_batch_gradient(tmp_path, foreign):
+    """Gradient accumulation on the drop-in autograd route under data parallelism: two micro-batches per rank, the first inside
+    TrainState.no_sync(), on two gloo ranks (one card) against four micro-batches of one process -- the mean-over-the-global-batch
+    gradient must agree to 1e-5 of its max.  Without no_sync the first micro-batch would be reduced twice (x world); with foreign
+    .grad tensors (not views of the flat buffer) the gradients go through autograd and are averaged by the fallback all-reduce."""
+    import torch.multiprocessing as mp
+    _ddp_accum_rank(0, 1, 0, str(tmp_path / "g1.npy"), foreign)
+    mp.spawn(_ddp_accum_rank, args=(2, 29577 + int(foreign), str(tmp_path / "g2.npy"), foreign), nprocs=2, join=True)
+    g1, g2 = np.load(tmp_path / "g1.npy"), np.load(tmp_path / "g2.npy")
+    assert np.abs(g1).max() > 0
+    assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max(), np.abs(g1 - g2).max() / np.abs(g1).max()
+
+
 def test_c5_per_gpu_shape_bf16_vs_fp32_mode():
     """BASELINE configs[4]'s per-GPU shape (256 px, batch 4, base 128, (1,2,2)): one loss + backward in bf16 mode against the fp32
     parity mode of the same library (itself checked against the oracle at the sizes above) -- loss, eps and every gradient

@@ -86,8 +86,8 @@ sm = DDIMSampler(NoiseScheduler(1000, "cosine", dev), 0.0)
 orig = [synth.synth_image(i, S).astype(np.float32).transpose(2, 0, 1) / 127.5 - 1.0 for i in range(B)]
 
 
-def run(weights, dtype="fp32"):
-    n = CLIPCondUNet(512, 128, (1, 2, 2), dtype=dtype).to(dev).eval()
+def run(weights, dtype="fp32", rounding="phases"):
+    n = CLIPCondUNet(512, 128, (1, 2, 2), dtype=dtype, weight_rounding=rounding).to(dev).eval()
     n.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()})
     x = sm.sample(n, z, (B, 3, S, S), steps=T, x_T=xT)
     torch.cuda.synchronize()
@@ -99,8 +99,8 @@ x32, p32 = run(sd)
 print(f"fp32 weights, fp32 arithmetic: PSNR mean {p32.mean():.4f}")
 
 
-def report(name, weights, dtype="fp32"):
-    x, ps = run(weights, dtype)
+def report(name, weights, dtype="fp32", rounding="phases"):
+    x, ps = run(weights, dtype, rounding)
     rel = (ps - p32) / p32
     print(f"{name:58s} PSNR {ps.mean():.4f}  rel delta mean {rel.mean():+.3e} max|.| {np.abs(rel).max():.3e}  {'PASS' if np.abs(rel).max() <= 1e-3 else 'fail'}"
           f"  mean-abs vs fp32 {float((x - x32).abs().mean()):.4f}  std {float(x.clamp(-1, 1).std()):.5f}", flush=True)
@@ -121,8 +121,11 @@ report("bf16 hi + lo", with_rounding(bf16_hilo, conv_keys))
 dif = {k: bf16_diffused(sd[k], k.startswith("up.") and sd[k].shape[2] == 4) for k in conv_keys}
 report("bf16, error diffused per output channel (cin, ky, kx)", {**sd, **dif})
 print("--- bf16 MODE (bf16 storage + bf16 MFMA) on the same weights")
-report("bf16 mode, fp32 checkpoint (RNE in ccn_commit_params)", sd, "bf16")
-report("bf16 mode, checkpoint pre-rounded with error diffusion", {**sd, **dif}, "bf16")
+report("bf16 mode, weight_rounding='nearest' (RNE in ccn_commit_params)", sd, "bf16", "nearest")
+report("bf16 mode, weight_rounding='diffused' (within the output channel)", sd, "bf16", "diffused")
+report("bf16 mode, weight_rounding='phases' (+ along the DDIM steps, 4 versions)", sd, "bf16", "phases")
+if "--bf16-only" in sys.argv:
+    sys.exit(0)
 print("--- under error diffusion: which levels still carry the shift (fp32 arithmetic; this level kept fp32 / stored as fp16)")
 levels = []
 for k in conv_keys:
