@@ -33,7 +33,7 @@ import torch
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def main() -> None:
@@ -54,6 +54,8 @@ def main() -> None:
     ap.add_argument("--cpu-steps", type=int, default=50, help="most DDIM steps of the CPU-baseline sample (batch 1)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise torch.distributed (RCCL) even at --gpus 1: barrier / all-gather / all-reduce of the N > 1 route run on one GPU")
+    ap.add_argument("--weight-rounding", choices=["phases", "diffused", "nearest"], default="phases",
+                    help="bf16 mode: how ccn_commit_params rounds the conv weights (A/B runs; the default is the library's)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (bf16 vs the reference's golden / fp32 mode, PSNR delta)")
     args = ap.parse_args()
 
@@ -91,7 +93,7 @@ def main() -> None:
     ch_mult = tuple(int(v) for v in args.ch_mult.split(","))
     B, S, T = args.batch, args.size, args.ddim_steps
     sd = synth.synth_state_dict(synth.unet_param_spec(512, args.base, ch_mult))
-    net = CLIPCondUNet(512, args.base, ch_mult, dtype=args.dtype).to(dev).eval()
+    net = CLIPCondUNet(512, args.base, ch_mult, dtype=args.dtype, weight_rounding=args.weight_rounding).to(dev).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     idx = list(range(rank * B, rank * B + B))
     z = torch.from_numpy(synth.synth_z(world * B)[rank * B:rank * B + B]).to(dev)

@@ -827,7 +827,7 @@ int build_plan(ccn_handle_s* h, Plan* plan, void* ws, bool measure)
                         k.x_state = sc.x_state; k.eps_out = sc.eps_out; k.do_ddim = sc.do_ddim;
                         k.c0 = sc.c[0]; k.c1 = sc.c[1]; k.c2 = sc.c[2]; k.c3 = sc.c[3];
                         k.noise = sc.noise; k.sigma = sc.sigma;
-                        return launch_head2(k, ab, wf, scratch, s);
+                        return launch_head2(k, ab, wf, scratch, sc.step, s);
                     };
                     plan->ops.push_back(std::move(Lh));
                     break;
@@ -988,9 +988,9 @@ extern "C" {
 
 const char* ccn_last_error(void) { return g_err.c_str(); }
 #ifdef CCN_DIAG
-const char* ccn_version(void) { return "ccn_hip 0.2 (gfx950, diagnostics build)"; }
+const char* ccn_version(void) { return "ccn_hip 0.3 (gfx950, diagnostics build)"; }
 #else
-const char* ccn_version(void) { return "ccn_hip 0.2 (gfx950)"; }
+const char* ccn_version(void) { return "ccn_hip 0.3 (gfx950)"; }
 #endif
 
 int ccn_create(const ccn_config_t* cfg, ccn_handle_t* out)
@@ -1104,7 +1104,7 @@ int ccn_commit_params(ccn_handle_t h)
     for (auto& m : h->host_ph) m.clear();
     const bool phases = c.dtype == CCN_DTYPE_BF16 && h->weight_rounding == CCN_ROUND_DIFFUSED_PHASES;
     if (c.dtype == CCN_DTYPE_BF16 && h->weight_rounding != CCN_ROUND_NEAREST) {
-        // (the head keeps fp32 weights: head_prep_kernel scales them per sample and splits them into bf16 hi + lo)
+        // (the head keeps fp32 weights: head_prep_kernel scales them per sample and rounds them with a carry along the steps)
         for (auto& p : h->params) {
             if (p.shape.size() != 4 || p.name == "out.weight") continue;
             if (phases) { diffuse_round_phases(h, p); continue; }

@@ -19,9 +19,9 @@ constexpr int HG_ROWS = 10, HG_COLS = 34, HG_PIX = HG_ROWS * HG_COLS;
 }
 
 // Per-sample head weights from out_norm's finalized (scale, shift) table (pair-interleaved, see GnCoef): fragments
-// [hi | lo][sample][k-step][lane][8 bf16] (lane (n = lane & 31, hh = lane >> 5) holds W'[16 s + 8 hh + e][n]) and S.  Grid (k-steps + 1, B).
+// [sample][k-step][lane][8 bf16] (lane (n = lane & 31, hh = lane >> 5) holds W'[16 s + 8 hh + e][n]) and S.  Grid (k-steps + 1, B).
 __global__ __launch_bounds__(512) void head_prep_kernel(const float2* __restrict__ ab, int C, const float* __restrict__ w, int Cout,
-                                                         unsigned short* __restrict__ wq, float* __restrict__ sq)
+                                                         unsigned short* __restrict__ wq, float* __restrict__ sq, float* __restrict__ carry, int step)
 {
     const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, ksteps = C / 16;
     const float* abf = (const float*)(ab + (size_t)b * C);         // channels (2p, 2p+1) -> {a, a, c, c}
@@ -31,14 +31,16 @@ __global__ __launch_bounds__(512) void head_prep_kernel(const float2* __restrict
         const int n = ln & 31, c = 16 * s + 8 * (ln >> 5) + e;
         float v = 0.f;
         if (n < N) { const int tap = n / Cout, co = n - tap * Cout; v = abf[4 * (c >> 1) + (c & 1)] * w[((size_t)co * C + c) * 9 + tap]; }
-        // W' as a bf16 hi + lo pair (two MFMAs per product in head_kernel): the head is HBM-bound, so the second MFMA is free, and
-        // the weights of THIS conv are the ones whose bf16 rounding moved the 50-step PSNR most (tools/weight_rounding_probe.py:
-        // with the head's weights exact the mean shift drops from 3.0e-4 to 0.5e-4)
-        const unsigned u = __float_as_uint(v);
+        // bf16 rounding with the error fed forward from DDIM step to DDIM step (the conv weights get the same treatment at commit
+        // time, diffuse_round_phases in ccn_api.hip): W' changes slowly along a trajectory, so independent rounding would repeat
+        // nearly the same error in all 50 steps; with the carry the running sum of the rounded weights tracks the running sum of W'.
+        // Step 0 (and ccn_forward) starts from a zero carry: plain round-to-nearest-even.
+        const size_t ci = ((size_t)b * ksteps + s) * 512 + tid;
+        const float t = v + (step > 0 ? carry[ci] : 0.f);
+        const unsigned u = __float_as_uint(t);
         const unsigned hi = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-        const unsigned ul = __float_as_uint(v - __uint_as_float(hi));
-        wq[((size_t)b * ksteps + s) * 512 + tid] = (unsigned short)(hi >> 16);
-        wq[((size_t)(gridDim.y + b) * ksteps + s) * 512 + tid] = (unsigned short)((ul + 0x7fffu + ((ul >> 16) & 1u)) >> 16);
+        carry[ci] = t - __uint_as_float(hi);
+        wq[ci] = (unsigned short)(hi >> 16);
     } else {
         // S[n] = sum_c shift[c] W[c][n]: 16 threads per n, fixed order
         const int n = tid >> 4, part = tid & 15;
@@ -87,44 +89,66 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsig
         const bool ok = p < HG_PIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
         base[t] = ok ? (unsigned)(((b * H + iy) * W + ix) * C + 8 * h) * 2u : OOB;
     }
-    f32x16 acc[MT];
+    if constexpr (NPASS == 1) {
+        // all loads first, then tile by tile: MFMAs, and the tile's G rows go to LDS while the next tile's loads are still landing
+        u32x4 wf[KSTEPS];                                          // B operand: W'_b fragments, [k-step][lane]
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        u32x4 wf[KP], wl[KP];                                      // B operand: W'_b fragments [k-step][lane], bf16 hi and lo parts
-#pragma unroll
-        for (int s = 0; s < KP; ++s) {
-            wf[s] = *(const u32x4*)(wq + ((size_t)b * KSTEPS + ps * KP + s) * 512 + lane * 8);
-            wl[s] = *(const u32x4*)(wq + ((size_t)(a.B + b) * KSTEPS + ps * KP + s) * 512 + lane * 8);
-        }
-        u32x4 af[MT][KP];
+        for (int s = 0; s < KSTEPS; ++s) wf[s] = *(const u32x4*)(wq + ((size_t)b * KSTEPS + s) * 512 + lane * 8);
+        u32x4 af[MT][KSTEPS];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int s = 0; s < KP; ++s) af[t][s] = __builtin_amdgcn_raw_buffer_load_b128(isrd, base[t], (ps * KP + s) * 32, 0);   // out of image -> zeros
+            for (int s = 0; s < KSTEPS; ++s) af[t][s] = __builtin_amdgcn_raw_buffer_load_b128(isrd, base[t], s * 32, 0);   // out of image -> zeros
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            if ((wave + 4 * t) * 32 >= HG_PIX) break;               // wave-uniform
+            const int mt = wave + 4 * t;
+            if (mt * 32 >= HG_PIX) break;                           // wave-uniform
+            f32x16 acc;
 #pragma unroll
-            for (int s = 0; s < KP; ++s)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][s]), __builtin_bit_cast(bf16x8, wl[s]), acc[t], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-            for (int s = 0; s < KP; ++s)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][s]), __builtin_bit_cast(bf16x8, wf[s]), acc[t], 0, 0, 0);
+            for (int s = 0; s < KSTEPS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][s]), __builtin_bit_cast(bf16x8, wf[s]), acc, 0, 0, 0);
+            // D: lane r = column n, register q = pixel row (q & 3) + 8 (q >> 2) + 4 h of the M tile
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pp = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (pp < HG_PIX) Gs[pp * HG_PITCH + r] = acc[q];
+            }
         }
-    }
+    } else {
+        f32x16 acc[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int mt = wave + 4 * t;
-        if (mt * 32 >= HG_PIX) break;                               // wave-uniform
-        // D: lane r = column n, register q = pixel row (q & 3) + 8 (q >> 2) + 4 h of the M tile
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int pp = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (pp < HG_PIX) Gs[pp * HG_PITCH + r] = acc[t][q];
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            u32x4 wf[KP];
+#pragma unroll
+            for (int s = 0; s < KP; ++s) wf[s] = *(const u32x4*)(wq + ((size_t)b * KSTEPS + ps * KP + s) * 512 + lane * 8);
+            u32x4 af[MT][KP];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int s = 0; s < KP; ++s) af[t][s] = __builtin_amdgcn_raw_buffer_load_b128(isrd, base[t], (ps * KP + s) * 32, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                if ((wave + 4 * t) * 32 >= HG_PIX) break;           // wave-uniform
+#pragma unroll
+                for (int s = 0; s < KP; ++s)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][s]), __builtin_bit_cast(bf16x8, wf[s]), acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int mt = wave + 4 * t;
+            if (mt * 32 >= HG_PIX) break;                           // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pp = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (pp < HG_PIX) Gs[pp * HG_PITCH + r] = acc[t][q];
+            }
         }
     }
     __syncthreads();
@@ -169,16 +193,20 @@ bool head2_supported(int dtype, int cin, int cout, int G)
     return dtype == 1 && cout * 9 <= 32 && cout <= 4 && (cin == 32 || cin == 64 || cin == 128 || cin == 192) && cin % g == 0;
 }
 
-size_t head2_scratch_bytes(int B, int C) { return (size_t)2 * B * (C / 16) * 512 * 2 + (size_t)B * 32 * 4 + 256; }
+// fragments (bf16) | rounding carry (fp32) | S
+size_t head2_scratch_bytes(int B, int C) { return (size_t)B * (C / 16) * 512 * 6 + (size_t)B * 32 * 4 + 512; }
 
-// `scratch`: head2_scratch_bytes(); `ab`: out_norm's finalized scale/shift table; `w_f32` the fp32 (Cout, C, 3, 3) weights on the device
-hipError_t launch_head2(const ConvArgs& a, const float2* ab, const float* w_f32, void* scratch, hipStream_t s)
+// `scratch`: head2_scratch_bytes(); `ab`: out_norm's finalized scale/shift table; `w_f32` the fp32 (Cout, C, 3, 3) weights on the device;
+// `step`: DDIM step index (0 restarts the rounding carry)
+hipError_t launch_head2(const ConvArgs& a, const float2* ab, const float* w_f32, void* scratch, int step, hipStream_t s)
 {
     if ((size_t)a.B * a.Hin * a.Win * a.Cin * 2 >= 0x7FFFFFF0u || a.Cin > 512) return hipErrorInvalidValue;
     const int ks = a.Cin / 16;
+    const size_t nfrag = (size_t)a.B * ks * 512;
     unsigned short* wq = (unsigned short*)scratch;
-    float* sq = (float*)((char*)scratch + (((size_t)2 * a.B * ks * 512 * 2 + 255) & ~(size_t)255));   // (hi fragments, lo fragments, S)
-    hipLaunchKernelGGL(head_prep_kernel, dim3(ks + 1, a.B), dim3(512), 0, s, ab, a.Cin, w_f32, a.Cout, wq, sq);
+    float* carry = (float*)((char*)scratch + ((nfrag * 2 + 255) & ~(size_t)255));
+    float* sq = carry + nfrag;
+    hipLaunchKernelGGL(head_prep_kernel, dim3(ks + 1, a.B), dim3(512), 0, s, ab, a.Cin, w_f32, a.Cout, wq, sq, carry, step);
     const unsigned grid = (unsigned)(a.B * ((a.Hin + 7) / 8) * ((a.Win + 31) / 32));
     switch (ks) {
         case 12: hipLaunchKernelGGL(head_kernel<12>, dim3(grid), dim3(256), 0, s, a, wq, sq, a.bias); break;

@@ -136,7 +136,7 @@ hipError_t launch_stem2(const ConvArgs& a, hipStream_t s);
 // dedicated head (ccn_head.hip): bf16 mode, out_norm folded into per-sample weights, the nine taps in the MFMA N dimension
 bool head2_supported(int dtype, int cin, int cout, int G);
 size_t head2_scratch_bytes(int B, int C);
-hipError_t launch_head2(const ConvArgs& a, const float2* ab, const float* w_f32, void* scratch, hipStream_t s);
+hipError_t launch_head2(const ConvArgs& a, const float2* ab, const float* w_f32, void* scratch, int step, hipStream_t s);
 
 // GroupNorm-apply + SiLU as its own pass (NHWC T -> NHWC T).  Used in front of convs whose input is re-staged by
 // several N tiles (Cout >= 256): the transform then runs once per element instead of once per (N tile x halo).

@@ -12,6 +12,7 @@
 //     through a per-wave LDS strip so that the NHWC stores are whole 256-byte pixel rows, and the next GroupNorm's
 //     statistics accumulate per lane over the wave's pixels and are reduced once.
 #include "ccn_device.h"
+#include <cstdlib>
 
 namespace ccn {
 
@@ -176,8 +177,11 @@ bool stem2_supported(int dtype, int cin, int cout, int G)
 int stem2_blocks(int H, int W, int* upw_out)
 {
     const int units = H * ((W + 31) / 32);
-    int upw = 4;
+    int upw = 8;                                                   // (sweep at C2, HIP events: 48.6 / 39.0 / 35.8 / 31.2 / 36.6 us for 1 / 2 / 4 / 8 / 16)
+    if (units < 4 * 8 * 16) upw = 4;
     if (units < 4 * 4 * 16) upw = 1;
+    static const char* e = diag_env("CCN_STEM_UPW");                // diagnostics build only: units per wave
+    if (e && atoi(e) > 0) upw = atoi(e);
     if (upw_out) *upw_out = upw;
     return (units + 4 * upw - 1) / (4 * upw);
 }

@@ -537,6 +537,9 @@ struct Walk {
         const int dt = tr->cfg.dtype;
         // algorithmic HBM bytes: pass 1 reads x and dA, pass 2 reads them again (+ the residual gradient) and writes dx
         mark(TF_GN_BWD, 0.0, (double)B * HW * x.C * tr->elem * (addend ? 6.0 : 5.0));
+        // (round 3: the three passes as ONE launch with one 1024-thread workgroup per (sample, group) for the levels below 256 px was
+        // built, parity-green, and 0.95 ms SLOWER per step (2.47 vs 1.53 ms for the family): a group's channels are 32-128 contiguous
+        // bytes per pixel, so 32 workgroups pull uncoalesced 32-byte segments at a few tens of GB/s each; docs/EXPERIMENTS.md R3.5)
         if (!ok(launch_gn_bwd_reduce(dt, x.p, dA, ab, stats, scr_gn, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_reduce")) return false;
         if (!ok(launch_gn_bwd_finalize(scr_gn, gg.nblk, B, x.C, cpg, G, (double)cpg * HW, par(n.pg), gstat, grad(n.pg), grad(n.pb), st), "gn_bwd_finalize")) return false;
         if (!ok(launch_gn_bwd_apply(dt, x.p, dA, ab, stats, gstat, addend, out, film_r, tr->F, scr_film, B, HW, x.C, cpg, G, silu ? 1 : 0, st), "gn_bwd_apply"))

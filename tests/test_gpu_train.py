@@ -73,9 +73,12 @@ def test_c1_shape_loss_and_all_gradients_fp32_match_reference_fixture_and_oracle
         assert np.abs(g[::step][:64].numpy() - GOLD[f"gsample/{k}"]).max() <= 2e-4 * scale + 1e-9, k
 
 
-@pytest.mark.parametrize("base,ch_mult,B,H,W", [(32, (1, 2), 3, 40, 72), (64, (1, 2, 2), 2, 64, 96), (96, (2,), 1, 36, 44)])
+@pytest.mark.parametrize("base,ch_mult,B,H,W", [(32, (1, 2), 3, 40, 72), (64, (1, 2, 2), 2, 64, 96), (96, (2,), 1, 36, 44),
+                                                  (128, (1, 2), 2, 32, 48), (128, (2, 2), 1, 24, 40)])
 def test_gradients_fp32_other_shapes(base, ch_mult, B, H, W):
-    """Ragged tiles, three levels, channel counts that are not a power of two, batch of one."""
+    """Ragged tiles, three levels, channel counts that are not a power of two, batch of one; and the widths of the BASELINE configs
+    (128 / 256 / 512 channels: GroupNorm groups of 16 / 32 / 64 channels, where the GroupNorm backward is the single-launch fused
+    kernel, gn_bwd_fused_kernel) -- every gradient tensor against the oracle."""
     sd = synth.synth_state_dict(synth.unet_param_spec(512, base, ch_mult))
     g = torch.Generator("cpu").manual_seed(B * 100 + H)
     x_t = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B))

@@ -5,7 +5,7 @@ set -u
 R=${1:-rXX}; O=gpurun_out/prof_$R; mkdir -p $O
 export TMPDIR=/tmp
 python bench.py --steps 5 --warmup 1 > $O/${R}_bench_bf16.json 2> $O/bench.err
-if [ -d .cmp_r01 ]; then (cd .cmp_r01 && python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline > ../$O/${R}_bench_bf16_round1_build_same_box.json 2>> ../$O/bench.err); fi
+if [ -d .cmp_r02 ]; then (cd .cmp_r02 && python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline > ../$O/${R}_bench_bf16_round2_build_same_box.json 2>> ../$O/bench.err); fi
 python bench.py --steps 2 --warmup 1 --dtype fp32 --no-cpu-baseline --no-parity > $O/${R}_bench_fp32.json 2>> $O/bench.err
 python bench_train.py > $O/${R}_bench_train_bf16.json 2>> $O/bench.err
 python tools/eval_e2e.py --n 256 > $O/${R}_eval_e2e.txt 2>&1
