@@ -17,6 +17,11 @@ workload) and, at N=1, `cpu_baseline` (the oracle timed on the host cores on a b
 from __future__ import annotations
 
 import argparse
+import os
+
+# the pool's host driver only supports dmabuf IPC: without this RCCL fails with "hipIpcGetMemHandle: invalid argument";
+# it is read when the HIP runtime starts, so it is set before torch is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import json
 import os
 import sys

@@ -14,6 +14,11 @@ kernels run on) and, at N = 1, `cpu_baseline` (the oracle's step -- torch-CPU au
 from __future__ import annotations
 
 import argparse
+import os
+
+# the pool's host driver only supports dmabuf IPC: without this RCCL fails with "hipIpcGetMemHandle: invalid argument";
+# it is read when the HIP runtime starts, so it is set before torch is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import json
 import os
 import sys

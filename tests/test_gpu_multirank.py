@@ -57,12 +57,13 @@ def test_bench_train_gpus_2_alone_reports_two_ranks():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 4 and np.isfinite(line["final_loss"])
 
 
-def _run_eval(store, ckpt, out_json, gpus, batch, dtype, size, steps):
+def _run_eval(store, ckpt, out_json, gpus, batch, dtype, size, steps, extra=(), env=None):
     cmd = [sys.executable, "-m", "clip_feature_codec.cli.eval", "--store_dir", str(store), "--weights", str(ckpt), "--size", str(size),
            "--steps", str(steps), "--batch", str(batch), "--seed", "7", "--device", "cuda", "--dtype", dtype, "--out_json", str(out_json)]
     if gpus is not None:
         cmd += ["--gpus", str(gpus)]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=900)
+    cmd += list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env or _env(), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count("Average PSNR:") == 1                   # rank 0 only
     return json.loads(Path(out_json).read_text())
@@ -99,3 +100,25 @@ def test_cli_eval_ranks_equal_single_process(tmp_path, n, batch, dtype, base, ch
                 assert abs(a[k] - b[k]) <= 1e-6 * abs(a[k]), (i, k, a[k], b[k])
         for k in ("lpips", "clip_sim"):
             assert (np.isnan(a[k]) and np.isnan(b[k])) or a[k] == b[k]
+
+
+def test_c3_workload_at_full_size_sharded_over_four_ranks_and_over_rccl(tmp_path):
+    """BASELINE configs[2] at its real size -- 64 records, 256 px, base 128, (1,2,2), 50 DDIM steps, bf16, batch 8 -- through cli.eval
+    (reference loop: cli/eval.py:56-86): (a) one process; (b) four fresh ranks on this one card (gloo between them; the process guard of
+    the box allows six), rank r taking records r::4 in two batches of 8, one all-gather; (c) one rank in an RCCL group (backend nccl).
+    Every record's PSNR / SSIM must be bit-equal in all three (independent units, per-record seeded start noise, batches of 8
+    everywhere).  What this cannot show is eight devices and xGMI: the driver's scaling run."""
+    n, size, steps, batch = 64, 256, 50, 8
+    store = tmp_path / "store"
+    synth.write_synth_store(store, n, size, write_clp=bitstream.write_bitstream)
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, (1, 2, 2)))
+    ckpt = tmp_path / "ckpt.pt"
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    one = _run_eval(store, ckpt, tmp_path / "one.json", None, batch, "bf16", size, steps)
+    four = _run_eval(store, ckpt, tmp_path / "four.json", 4, batch, "bf16", size, steps)
+    env = {k: v for k, v in _env().items() if k != "CCN_DIST_BACKEND"}
+    rccl = _run_eval(store, ckpt, tmp_path / "rccl.json", None, batch, "bf16", size, steps, extra=["--force-process-group"], env=env)
+    assert len(one) == len(four) == len(rccl) == n
+    for a, b, c in zip(one, four, rccl):
+        assert a["image"] == b["image"] == c["image"]
+        assert np.isfinite(a["psnr"]) and a["psnr"] == b["psnr"] == c["psnr"] and a["ssim"] == b["ssim"] == c["ssim"]
