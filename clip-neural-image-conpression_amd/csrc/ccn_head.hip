@@ -14,7 +14,8 @@
 namespace ccn {
 
 namespace {
-constexpr int HG_PITCH = 33;                                       // floats per halo pixel in LDS (32 + 1: conflict-free gathers)
+constexpr int HG_PITCH = 27;                                       // floats per halo pixel in LDS: the 27 useful columns (odd: conflict-free
+                                                                   // gathers); 36.7 KB per workgroup -> four workgroups per CU
 constexpr int HG_ROWS = 10, HG_COLS = 34, HG_PIX = HG_ROWS * HG_COLS;
 }
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(512) void head_prep_kernel(const float2* __restrict
 }
 
 template <int KSTEPS>
-__global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsigned short* __restrict__ wq, const float* __restrict__ sq,
+__global__ __launch_bounds__(256, 4) void head_kernel(const ConvArgs a, const unsigned short* __restrict__ wq, const float* __restrict__ sq,
                                                    const float* __restrict__ bias)
 {
     typedef __bf16 T;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsig
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int pp = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (pp < HG_PIX) Gs[pp * HG_PITCH + r] = acc[q];
+                if (pp < HG_PIX && r < HG_PITCH) Gs[pp * HG_PITCH + r] = acc[q];
             }
         }
     } else {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsig
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int pp = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (pp < HG_PIX) Gs[pp * HG_PITCH + r] = acc[t][q];
+                if (pp < HG_PIX && r < HG_PITCH) Gs[pp * HG_PITCH + r] = acc[t][q];
             }
         }
     }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvArgs a, const unsig
 bool head2_supported(int dtype, int cin, int cout, int G)
 {
     const int g = cin < G ? cin : G;
-    return dtype == 1 && cout * 9 <= 32 && cout <= 4 && (cin == 32 || cin == 64 || cin == 128 || cin == 192) && cin % g == 0;
+    return dtype == 1 && cout * 9 <= 27 && cout <= 3 && (cin == 32 || cin == 64 || cin == 128 || cin == 192) && cin % g == 0;
 }
 
 // fragments (bf16) | rounding carry (fp32) | S

@@ -383,6 +383,26 @@ def test_c4_architecture_four_levels_base192(synth):
     assert torch.isfinite(e16).all() and d < 2e-2, d
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 256, 256), (3, 200, 168)])
+def test_half_padded_n_tile_192_channels(synth, B, H, W):
+    """192-wide layers (C4's first level: N tiles of 128 + 64 channels) with more tiles than CUs: the consumer waves of the second N
+    tile whose 32 channels are all padding only keep the barrier protocol (ccn_conv_pr.hip, idle_w).  bf16 mode against the fp32 mode
+    (which runs other kernels), intermediates of both levels and eps; reference: models/unet.py:59-65 (widths), models/blocks.py:40-44."""
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 192, (1, 2)))
+    g = torch.Generator("cpu").manual_seed(B + H)
+    x = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B)); t = torch.randint(0, 1000, (B,), generator=g)
+    n32, n16 = make_net(sd, 192, (1, 2)), make_net(sd, 192, (1, 2), dtype="bf16")
+    e32 = n32(to_dev(x), to_dev(z), to_dev(t)); e16 = n16(to_dev(x), to_dev(z), to_dev(t))
+    for name, hh, ww in (("down.0", H, W), ("down.1", H, W), ("down.3", H // 2, W // 2), ("up.5", H, W)):
+        a32 = n32.native().read_activation(name, (B, 192, hh, ww)); a16 = n16.native().read_activation(name, (B, 192, hh, ww))
+        d = (a16 - a32).abs()
+        # a wrong channel / tile mapping is O(1) everywhere; bf16 rounding is O(1e-2) on activations of O(1-5)
+        assert float(d.max()) < 0.25 and float(d.mean()) < 1.5e-2, (name, float(d.max()), float(d.mean()))
+    d = maxerr(e16, e32)
+    assert torch.isfinite(e16).all() and d < 2e-2, d
+    n16.native().poll_errors()
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 72, 104), (8, 40, 48), (5, 136, 200), (2, 264, 136), (16, 128, 128)])
 def test_c2_architecture_odd_shapes(synth, c2_sd, B, H, W):
     """Batch / image sizes that change which kernel takes each layer (tile counts decide between the persistent kernel, its
