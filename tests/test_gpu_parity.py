@@ -469,3 +469,32 @@ def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
     # fp32 mode vs the reference on record 0: PSNR within 0.1 % follows from max-abs < 1e-3 (uint8 truncation moves few pixels)
     torch.cuda.synchronize()
     net16.native().poll_errors()                                # no device-side failure (split-K hand-off timeout) was flagged
+
+
+def test_weight_rounding_modes(synth, c2_sd):
+    """ccn_set_weight_rounding (bf16 mode).  Version 0 of 'phases' IS the 'diffused' rounding, and ccn_forward always uses version 0:
+    the two modes give bit-equal forwards; the fused sampler cycles the four versions, so from step 1 on its trajectory differs from
+    'diffused' -- by rounding-level amounts; 'nearest' differs from both already in one forward.  All three stay within the bf16 mode's
+    per-forward bound against the fp32 mode."""
+    B, S = 2, 64
+    g = torch.Generator("cpu").manual_seed(3)
+    x = to_dev(torch.randn((B, 3, S, S), generator=g)); z = to_dev(synth.synth_z(B)); t = to_dev(torch.tensor([900, 100]))
+    nets = {}
+    for mode in ("nearest", "diffused", "phases"):
+        n = CLIPCondUNet(z_dim=512, base=128, ch_mult=(1, 2, 2), dtype="bf16", weight_rounding=mode).to(DEV).eval()
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in c2_sd.items()}, strict=True)
+        nets[mode] = n
+    e = {m: n(x, z, t) for m, n in nets.items()}
+    e32 = make_net(c2_sd, 128, (1, 2, 2))(x, z, t)
+    assert torch.equal(e["diffused"], e["phases"])
+    assert not torch.equal(e["nearest"], e["diffused"])
+    for m in e:
+        assert maxerr(e[m], e32) < 2e-2, (m, maxerr(e[m], e32))
+    sampler = DDIMSampler(NoiseScheduler(1000, "cosine", DEV), 0.0)
+    xs = {m: sampler.sample(nets[m], z, (B, 3, S, S), steps=6, x_T=x) for m in ("diffused", "phases")}
+    d = float((xs["diffused"] - xs["phases"]).abs().max())
+    assert 0.0 < d < 0.1, d                                        # different versions from step 1 on, same model to rounding level
+    one = sampler.sample(nets["phases"], z, (B, 3, S, S), steps=1, x_T=x)
+    assert torch.equal(one, sampler.sample(nets["diffused"], z, (B, 3, S, S), steps=1, x_T=x))     # step 0 = version 0
+    with pytest.raises(ValueError):
+        CLIPCondUNet(z_dim=512, base=128, ch_mult=(1, 2, 2), dtype="bf16", weight_rounding="stochastic").to(DEV).native()
