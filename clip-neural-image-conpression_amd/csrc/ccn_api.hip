@@ -341,6 +341,27 @@ void diffuse_round_phases(ccn_handle_s* h, const ParamInfo& p)
     }
 }
 
+}  // namespace
+// Host-only arithmetic of the bf16 weight rounding, exported for tests/test_host_logic.py (not part of include/ccn_hip.h; no GPU
+// involved): `w` is a Conv2d (O, I, taps) or -- convT != 0 -- a ConvTranspose2d (I, O, 4, 4) weight; out[p] receives version p of
+// `phases` versions (phases == 1: the plain error-diffused rounding), each bf16-representable fp32.
+extern "C" int ccn_internal_round_weights(const float* w, int O, int I, int taps, int convT, int phases, float* out)
+{
+    if (!w || !out || O <= 0 || I <= 0 || phases < 1 || phases > 8 || (convT && taps != 16)) return 1;
+    const size_t n = (size_t)O * I * taps;
+    std::vector<float> orig(w, w + n);
+    std::vector<double> sum(n, 0.0);
+    for (int k = 0; k < phases; ++k) {
+        std::vector<float> wk(n);
+        for (size_t i = 0; i < n; ++i) wk[i] = (float)((double)(k + 1) * (double)orig[i] - sum[i]);
+        if (convT) diffuse_round_convT(wk, I, O); else diffuse_round_conv(wk, O, I, taps);
+        for (size_t i = 0; i < n; ++i) sum[i] += (double)wk[i];
+        std::memcpy(out + (size_t)k * n, wk.data(), n * 4);
+    }
+    return 0;
+}
+namespace {
+
 // element (tap, o, i) of the packed [taps][Cout_pad][Cin_pad] tensor
 template <typename F>
 int pack_and_upload(ccn_handle_s* h, ConvW& cw, int taps, F&& at)

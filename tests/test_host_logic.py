@@ -185,3 +185,64 @@ def test_uint8_metric_path_equals_the_float_path(tmp_path):
     got = cli_eval.metric_row_u8(cli_eval.original_u8(str(path), 48), recon_u8)
     assert got[0] == want[0] and got[1] == want[1] and np.isnan(got[2]) and np.isnan(got[3])
     assert 2 <= cli_eval.default_workers(1) <= 16 and cli_eval.default_workers(64) == 2
+
+
+def test_bf16_weight_rounding_arithmetic_on_the_host():
+    """ccn_set_weight_rounding's arithmetic (ccn_api.hip: diffuse_round_conv / _convT / _phases), run on the HOST through an internal
+    export of the library (no GPU call).  Properties the PSNR gate relies on:
+      * every rounded weight is bf16-representable and within one bf16 ulp (at the tensor's largest magnitude: a small weight
+        absorbs the carried error of a large neighbour) of the fp32 weight;
+      * within every output channel, EVERY prefix sum of the rounded weights along (cin, ky, kx) is within half an ulp of the fp32
+        prefix sum (independent rounding drifts like a random walk: ~sqrt(K) half-ulps);
+      * along the phases, the running sum W_0 + ... + W_k has the same property against (k + 1) W, so the MEAN weight over a period of
+        four steps is four times closer to the fp32 weight than one rounding;
+      * ConvTranspose2d: the diffusion runs per (output channel, output parity) over the four taps that parity sees."""
+    import ctypes
+    from clip_feature_codec import _native
+    lib = ctypes.CDLL(str(_native.LIB_PATH))
+    fn = lib.ccn_internal_round_weights
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+
+    def bf16_ok(a):
+        return np.all((a.view(np.uint32) & 0xFFFF) == 0)
+
+    def ulp(a):                                    # bf16 ulp at the magnitude of a (8 significant bits)
+        return 2.0 ** (np.floor(np.log2(np.maximum(np.abs(a), 1e-30))) - 7)
+
+    O, I, taps, P = 24, 40, 9, 4
+    w = (rng.standard_normal((O, I, taps)) / np.sqrt(3.0 * I * taps)).astype(np.float32)
+    out = np.empty((P, O, I, taps), np.float32)
+    assert fn(w.ctypes.data, O, I, taps, 0, P, out.ctypes.data) == 0
+    assert bf16_ok(out)
+    assert np.all(np.abs(out[0] - w) <= ulp(np.abs(w).max()) * 1.001)
+    bound = 0.5 * ulp(np.abs(w).max()) * 1.001
+    run = np.zeros_like(w, dtype=np.float64)
+    for k in range(P):
+        run += out[k]
+        drift = np.cumsum((run - (k + 1) * w.astype(np.float64)).reshape(O, -1), axis=1)
+        assert np.abs(drift).max() <= bound, (k, np.abs(drift).max(), bound)
+    # independent rounding for comparison: its prefix sums wander several half-ulps away
+    import torch
+    rne = torch.from_numpy(w).to(torch.bfloat16).float().numpy().astype(np.float64)
+    assert np.abs(np.cumsum((rne - w).reshape(O, -1), axis=1)).max() > 3 * bound
+    # the period mean is closer to the fp32 weight than a single rounding (rms over all weights)
+    e1 = np.sqrt(np.mean((out[0] - w) ** 2)); e4 = np.sqrt(np.mean((out.mean(0) - w) ** 2))
+    assert e4 < 0.45 * e1, (e1, e4)
+    # phases == 1 is the plain diffused rounding = version 0 of the phased one
+    one = np.empty((1, O, I, taps), np.float32)
+    assert fn(w.ctypes.data, O, I, taps, 0, 1, one.ctypes.data) == 0 and np.array_equal(one[0], out[0])
+
+    # ConvTranspose2d (I, O, 4, 4): per (output channel, parity) over (cin, the parity's 2x2 taps)
+    Ci, Co = 20, 12
+    wt = (rng.standard_normal((Ci, Co, 4, 4)) / np.sqrt(3.0 * Ci * 4)).astype(np.float32)
+    ot = np.empty((1, Ci, Co, 4, 4), np.float32)
+    assert fn(wt.ctypes.data, Co, Ci, 16, 1, 1, ot.ctypes.data) == 0 and bf16_ok(ot)
+    kk2 = [[1, 3], [0, 2]]                          # kernel indices feeding even / odd outputs (stride 2, padding 1)
+    bt = 0.5 * ulp(np.abs(wt).max()) * 1.001
+    for par in range(4):
+        ky, kx = kk2[par >> 1], kk2[par & 1]
+        sel = np.stack([(ot[0] - wt.astype(np.float64))[:, :, ky[t >> 1], kx[t & 1]] for t in range(4)], axis=-1)   # (Ci, Co, 4)
+        drift = np.cumsum(np.transpose(sel, (1, 0, 2)).reshape(Co, -1), axis=1)
+        assert np.abs(drift).max() <= bt, (par, np.abs(drift).max(), bt)
