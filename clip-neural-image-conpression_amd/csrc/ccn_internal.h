@@ -144,7 +144,8 @@ bool conv_wants_preact(int kind, int bn, int n_nt);
 hipError_t launch_gn_act(int dtype, const void* x, const float2* ab, void* y, int B, int HW, int C, hipStream_t s);
 // the same with the GroupNorm finalize of the input folded in (partial sums -> scale/shift inside every workgroup)
 hipError_t launch_gn_act_fused(int dtype, const void* x, void* y, int B, int HW, int C, const float2* part, int G, int n_sp, int n_nt,
-                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s);
+                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s,
+                               float2* ab_out = nullptr, float2* stats_out = nullptr);
 
 // ---- GroupNorm finalize: partial sums -> per-(b,channel) scale/shift --------------------------------
 hipError_t launch_gn_finalize(const float2* part, int B, int G, int n_sp, int n_nt, int bn, int cpg, int C,

@@ -501,10 +501,13 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const T* __restrict__ x, co
 // The same pass with the GroupNorm finalize folded in: every workgroup first reduces the producer's partial sums of its
 // sample (G groups x a few hundred slots, L2 resident; a fixed summation order, so deterministic) and
 // forms its threads' scale/shift in registers -- one launch and one ~5 us dependency step less per pre-activated conv.
+// `ab_out` / `stats_out` (training forward, else null): the first workgroup of every sample also writes the scale / shift table and
+// (mean, rstd) per group, which the backward pass and the weight-gradient kernel read -- the separate gn_stats launch disappears.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_act_fused_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C,
                                                             const float2* __restrict__ part, int G, int nslot, int n_nt, int bn, int cpg,
-                                                            double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps)
+                                                            double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float2* __restrict__ ab_out, float2* __restrict__ stats_out)
 {
     constexpr int EPC = Vec16<T>::EPC;
     __shared__ double st[64][2];
@@ -526,6 +529,15 @@ __global__ __launch_bounds__(256) void gn_act_fused_kernel(const T* __restrict__
         if (lane == 0) { st[g][0] = mean; st[g][1] = rstd; }
     }
     __syncthreads();
+    if (ab_out && blockIdx.x == 0) {
+        for (int c = tid; c < C; c += 256) {
+            const int g = c / cpg;
+            const double sc = (double)gamma[c] * st[g][1];
+            float* const row = (float*)(ab_out + (size_t)b * C) + 4 * (c >> 1) + (c & 1);      // pair-interleaved (GnCoef::load)
+            row[0] = (float)sc; row[2] = (float)((double)beta[c] - st[g][0] * sc);
+        }
+        if (tid < G) stats_out[b * G + tid] = make_float2((float)st[tid][0], (float)st[tid][1]);
+    }
     if (!act) return;
     GnCoef<T> gk;
 #pragma unroll
@@ -541,14 +553,15 @@ __global__ __launch_bounds__(256) void gn_act_fused_kernel(const T* __restrict__
     }
 }
 hipError_t launch_gn_act_fused(int dtype, const void* x, void* y, int B, int HW, int C, const float2* part, int G, int n_sp, int n_nt,
-                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s)
+                               int bn, int cpg, double count, const float* gamma, const float* beta, float eps, hipStream_t s,
+                               float2* ab_out, float2* stats_out)
 {
     const int epc = dtype == 0 ? 4 : 8, nsl = C / epc;
     if (nsl > 256 || nsl <= 0 || G > 64) return hipErrorInvalidValue;
     const int pstep = 256 / nsl;
     const dim3 grid((HW + 4 * pstep - 1) / (4 * pstep), B);
-    if (dtype == 0) hipLaunchKernelGGL(gn_act_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps);
-    else hipLaunchKernelGGL(gn_act_fused_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps);
+    if (dtype == 0) hipLaunchKernelGGL(gn_act_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps, ab_out, stats_out);
+    else hipLaunchKernelGGL(gn_act_fused_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, HW, C, part, G, n_sp * n_nt, n_nt, bn, cpg, count, gamma, beta, eps, ab_out, stats_out);
     return hipGetLastError();
 }
 

@@ -389,6 +389,26 @@ struct Walk {
         mark(TF_PREACT, 0.0, 2.0 * B * t.H * t.W * t.C * tr->elem);
         return ok(launch_gn_act(tr->cfg.dtype, t.p, ab, out.p, B, t.H * t.W, t.C, st), "gn_act");
     }
+    // GroupNorm statistics AND the pre-activated tensor SiLU(GN(t)) in one launch (round 3: 29 gn_stats launches of a step gone):
+    // every workgroup of the pass reduces the producer's partial sums itself, the first one of each sample also writes the scale /
+    // shift table and (mean, rstd) for the backward pass
+    bool gn_fwd_preact(const TT& t, const TNorm& n, float2*& ab, float2*& stats, const TT& out)
+    {
+        const int G = groups_for(t.C), cpg = t.C / G;
+        ab = (float2*)take((size_t)B * t.C * sizeof(float2));
+        stats = (float2*)take((size_t)B * G * sizeof(float2));
+        if (!launch) return true;
+        // every workgroup redoes the reduction of G x slots partial sums: worth it while that is a few KB (below the 256-pixel level);
+        // at 256 px (256+ slots per group, 1024 workgroups per sample) the separate 5-us statistics launch stays
+        if ((long)t.n_sp * t.n_nt > 128) {
+            mark(TF_GN_STATS);
+            if (!ok(launch_gn_stats(t.part, B, G, t.n_sp, t.n_nt, t.bn, cpg, t.C, (double)cpg * t.H * t.W, par(n.pg), par(n.pb), 1e-5f, ab, stats, st), "gn_stats")) return false;
+            return preact(t, ab, out);
+        }
+        mark(TF_PREACT, 0.0, 2.0 * B * t.H * t.W * t.C * tr->elem);
+        return ok(launch_gn_act_fused(tr->cfg.dtype, t.p, out.p, B, t.H * t.W, t.C, t.part, G, t.n_sp, t.n_nt, t.bn, cpg, (double)cpg * t.H * t.W,
+                                      par(n.pg), par(n.pb), 1e-5f, st, ab, stats), "gn_act_fused");
+    }
     bool gn_fwd(const TT& t, const TNorm& n, float2*& ab, float2*& stats)
     {
         const int G = groups_for(t.C), cpg = t.C / G;
@@ -442,12 +462,12 @@ struct Walk {
                     static const bool no_pre = diag_env("CCN_TRAIN_NO_PREACT") != nullptr;       // A/B switch
                     ResSave s; s.x = x;
                     s.pre = !no_pre && r.C / (tr->elem == 2 ? 8 : 4) <= 256;
-                    if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;
-                    if (s.pre) { s.xa = new_tensor(r.C, x.H, x.W); if (!preact(x, s.ab1, s.xa)) return false; }
+                    if (s.pre) { s.xa = new_tensor(r.C, x.H, x.W); if (!gn_fwd_preact(x, r.n1, s.ab1, s.st1, s.xa)) return false; }
+                    else if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;
                     s.y = new_tensor(r.C, x.H, x.W);
                     if (!conv_fwd(r.c1, s.pre ? s.xa : x, s.y, s.pre ? nullptr : s.ab1, film ? film + r.film_off : nullptr, nullptr, true)) return false;
-                    if (!gn_fwd(s.y, r.n2, s.ab2, s.st2)) return false;
-                    if (s.pre) { s.ya = new_tensor(r.C, x.H, x.W); if (!preact(s.y, s.ab2, s.ya)) return false; }
+                    if (s.pre) { s.ya = new_tensor(r.C, x.H, x.W); if (!gn_fwd_preact(s.y, r.n2, s.ab2, s.st2, s.ya)) return false; }
+                    else if (!gn_fwd(s.y, r.n2, s.ab2, s.st2)) return false;
                     s.o = new_tensor(r.C, x.H, x.W);
                     if (!conv_fwd(r.c2, s.pre ? s.ya : s.y, s.o, s.pre ? nullptr : s.ab2, nullptr, &x, true)) return false;
                     rs.push_back(s);
