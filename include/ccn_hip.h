@@ -35,7 +35,7 @@ extern "C" {
 #define CCN_ESTATE        5   /* call order violated                         */
 
 #define CCN_DTYPE_F32     0   /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode        */
-#define CCN_DTYPE_BF16    1   /* bf16 storage, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate  */
+#define CCN_DTYPE_BF16    1   /* bf16 storage, bf16 MFMA (v_mfma_f32_16x16x32_bf16 / 32x32x16), fp32 accumulate */
 
 #define CCN_MAX_MULT      8
 
