@@ -661,11 +661,7 @@ struct PlanBuilder {
     // cheaper than the ~6.5 us of a finalize launch + kernel boundary -- true below the 256-pixel level at C2.
     bool in_kernel_stats(const TensorRef& t, int C) const
     {
-#ifdef CCN_AB_NO_INSTAT
-        static const bool off = true;
-#else
-        static const bool off = diag_env("CCN_NO_INSTAT") != nullptr;
-#endif
+        static const bool off = diag_env("CCN_NO_INSTAT") != nullptr;       // diagnostics build only
         if (off || h->cfg.dtype != CCN_DTYPE_BF16 || t.n_sp <= 0 || t.C != C) return false;
         const int G = groups_for(C), cpg = C / G;
         if (G != 8 || (cpg % 8) != 0) return false;
@@ -749,11 +745,7 @@ struct PlanBuilder {
         // images/s against pre-pass + finalize-free conv; CCN_PREACT_PR=1 restores the pre-pass in front of it for A/B runs)
         static const bool preact_pr = diag_env("CCN_PREACT_PR") != nullptr;
         const bool pre = conv_wants_preact(r.c1.kind, r.c1.BN, r.c1.Cout_pad / r.c1.BN) && r.C / (h->elem == 2 ? 8 : 4) <= 256 &&
-#ifdef CCN_AB_PREPASS4
-                         (preact_pr || r.c1.Cout_pad / r.c1.BN >= 4 || !will_use_pr(r.c1, x.H, x.W));
-#else
                          (preact_pr || r.c1.Cout_pad / r.c1.BN >= 6 || !will_use_pr(r.c1, x.H, x.W));
-#endif
         static const bool fuse_act = !diag_env("CCN_NO_FUSED_GNACT");       // finalize folded into the pre-pass (A/B switch)
         const bool f1 = pre && fuse_act && x.n_sp > 0, f2 = pre && fuse_act;     // (n_sp, not the pointer: null while measuring)
         TensorRef y = new_tensor(r.C, x.H, x.W);

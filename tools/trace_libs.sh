@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch kernel trace of one UNet forward for several library builds: trace_libs.sh <tag> ...  ("-" = product library)
-# (timing experiments: -DCCN_AB_PROD_IDLE / -DCCN_AB_WHOT builds produce wrong results on purpose)
+# (libraries built with `make ab V=_x EXTRA=-D...`; the round-2 timing switches it was used with are gone from the source, docs/EXPERIMENTS.md)
 L=/root/repo/clip-neural-image-conpression_amd/csrc
 export TMPDIR=/tmp
 for v in "$@"; do
