@@ -725,13 +725,16 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                     }
                     if (s_ + PF < NG * NSG) rload(s_ + PF);
                     int nm = 0;
+                    // The six (dy, c) weight fragments are visited back and forth from step to step: a step ends on the fragment the next
+                    // one starts with, so ONE MFMA operand changes per MFMA instead of 7 per 6 -- less operand toggling, less energy per
+                    // MFMA on a power-limited chip: +0.4 ... +0.75 % images/s (three interleaved A/B rounds).  Every accumulator quarter
+                    // still receives its contributions in the same order (one MFMA per quarter per step): results are bit-identical.
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
+                    for (int q6 = 0; q6 < 6; ++q6) {
+                        const int o = (s_ & 1) ? 5 - q6 : q6;
+                        const int dy = o >> 1, c = o & 1;
                         const int i = hh - dy;
-                        if (i >= 0 && i < TH) {
-#pragma unroll
-                            for (int c = 0; c < 2; ++c) { mfma16q(acc[i], p * 2 + c, bq[g & 1][dy][c], rw[s_ % WIN]); ++nm; }
-                        }
+                        if (i >= 0 && i < TH) { mfma16q(acc[i], p * 2 + c, bq[g & 1][dy][c], rw[s_ % WIN]); ++nm; }
                     }
 #pragma unroll
                     for (int m = 0; m < 6; ++m) {
