@@ -858,10 +858,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 if (j + 1 < NSTEP) frag(j + 1, av[(j + 1) & 1]);
                 // operands swapped (weights as the MFMA A operand): a lane's accumulator registers run over output
                 // channels ((q&3) + 8*(q>>2) + 4*h) of pixel r, i.e. 4 consecutive channels per register quad
+                // (the second weight fragment walks the row fragments backwards: it starts on the one the first ended on -- one operand
+                // change less per step, bit-identical results; see the 3x3 form)
 #pragma unroll
                 for (int jn = 0; jn < NF; ++jn)
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) mfma16<T>(acc[i][jn], bq[j % D][jn], av[j & 1][i]);
+                    for (int ii = 0; ii < MF; ++ii) { const int i = (jn & 1) ? MF - 1 - ii : ii; mfma16<T>(acc[i][jn], bq[j % D][jn], av[j & 1][i]); }
                 // one MFMA, then (in its shadow) one weight load, one LDS fragment read and a little address math of the next step
 #pragma unroll
                 for (int m = 0; m < MF * NF; ++m) {
