@@ -303,7 +303,7 @@ def main() -> None:
                        "global_batch": world * B, "parallelism": f"dp{world} (independent batches, no collective in the loop)",
                        "graph": "hipGraph, one replay per step",
                        "bf16_weight_rounding": (args.weight_rounding + " (ccn_set_weight_rounding: error diffusion within the output channel"
-                                                " and along the DDIM steps, four bf16 versions of every conv weight used in turn)"
+                                                " and along the DDIM steps, eight bf16 versions of every conv weight used in turn)"
                                                 if args.weight_rounding == "phases" else args.weight_rounding) if args.dtype == "bf16" else None,
                        "steps_in_flight": nfl,
                        ("value_with_two_steps_in_flight" if nfl == 1 else "value_with_one_step_in_flight"): other_value},

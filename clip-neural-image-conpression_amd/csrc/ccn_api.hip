@@ -65,8 +65,8 @@ struct ConvW {
     // bf16 mode, CCN_ROUND_DIFFUSED_PHASES: further roundings of the same weights, used by DDIM step i as version i % nphase
     // (version 0 = w / wfrag above); see diffuse_round_phases()
     int nphase = 1;
-    void* w_ph[3] = {nullptr, nullptr, nullptr};
-    void* wfrag_ph[3] = {nullptr, nullptr, nullptr};
+    void* w_ph[7] = {};
+    void* wfrag_ph[7] = {};
 };
 struct NormW { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
 struct ResW {
@@ -172,7 +172,8 @@ struct ccn_handle_s {
     int F = 0;                          // rows of the concatenated FiLM linear
     int G = 8;
     int weight_rounding = CCN_ROUND_DIFFUSED_PHASES;   // how bf16 mode rounds the conv weights in ccn_commit_params (ccn_set_weight_rounding)
-    std::map<std::string, std::vector<float>> host_ph[3];   // versions 1..3 of the rounded conv weights until commit
+    std::map<std::string, std::vector<float>> host_ph[7];   // versions 1.. of the rounded conv weights until commit
+    int nphase = 1;                                     // versions per conv weight of the committed model (diffuse_round_phases)
     std::vector<std::unique_ptr<Plan>> plans;
     hipStream_t cap_stream = nullptr;
     unsigned* err_host = nullptr;       // pinned, device-mapped error word the kernels OR into (ConvArgs::err)
@@ -313,13 +314,20 @@ void diffuse_round_convT(std::vector<float>& w, int I, int O)                 //
 // CCN_ROUND_DIFFUSED_PHASES: error diffusion ALSO ALONG THE DDIM STEPS.  A rounded weight is a static perturbation of the model:
 // the same error acts in each of the 50 evaluations of one trajectory, and because x changes slowly from step to step its effect
 // adds up coherently -- that, not the size of one forward's error, is what moved the PSNR (zero-mean noise of twice the size drawn
-// afresh every step moves it 30x less; tools/bf16_bias_probe.py).  So the sampler uses kPhases roundings W_0 .. W_{n-1} of every conv
+// afresh every step moves it 30x less; tools/bf16_bias_probe.py).  So the sampler uses n roundings W_0 .. W_{n-1} of every conv
 // weight in turn (step i takes version i % n), built with the rounding error fed forward from version to version:
 //     W_k = round( (k + 1) W - (W_0 + ... + W_{k-1}) )      (each `round` = the spatial diffusion above)
 // Every partial sum W_0 + ... + W_k stays within half a bf16 ulp of (k + 1) W: the MEAN weight over a period is accurate to
 // ulp / (2n) instead of ulp / 2, and what remains alternates in sign from step to step with period <= n steps, which the sampler
 // averages out.  Costs n copies of the bf16 weights in HBM (65 MB each at C2) and nothing at run time: each step reads one version.
-constexpr int kPhases = 4;
+// n = 8 (bench workload, mean / max PSNR delta per record: 1 version 5.2e-4 / 8.6e-4, 4 versions 4.5e-4 / 9.4e-4, 8 versions
+// 3.9e-4 / 8.5e-4); 4 for models above 100 M conv weights (C4: 816 M -- commit time and 1.6 GB per version).
+int phases_for(const ccn_handle_s* h)
+{
+    size_t total = 0;
+    for (auto& p : h->params) if (p.shape.size() == 4) total += p.numel();
+    return total > (size_t)100000000 ? 4 : 8;
+}
 void diffuse_round_phases(ccn_handle_s* h, const ParamInfo& p)
 {
     auto& w0 = h->host.at(p.name);
@@ -332,7 +340,7 @@ void diffuse_round_phases(ccn_handle_s* h, const ParamInfo& p)
     round_one(w0);
     std::vector<double> sum(orig.size());
     for (size_t i = 0; i < orig.size(); ++i) sum[i] = (double)w0[i];
-    for (int k = 1; k < kPhases; ++k) {
+    for (int k = 1; k < h->nphase; ++k) {
         std::vector<float> wk(orig.size());
         for (size_t i = 0; i < orig.size(); ++i) wk[i] = (float)((double)(k + 1) * (double)orig[i] - sum[i]);
         round_one(wk);
@@ -1116,6 +1124,7 @@ int ccn_commit_params(ccn_handle_t h)
     int rc;
     for (auto& m : h->host_ph) m.clear();
     const bool phases = c.dtype == CCN_DTYPE_BF16 && h->weight_rounding == CCN_ROUND_DIFFUSED_PHASES;
+    h->nphase = phases ? phases_for(h) : 1;
     if (c.dtype == CCN_DTYPE_BF16 && h->weight_rounding != CCN_ROUND_NEAREST) {
         // (the head keeps fp32 weights: head_prep_kernel scales them per sample and rounds them with a carry along the steps)
         for (auto& p : h->params) {
@@ -1131,7 +1140,7 @@ int ccn_commit_params(ccn_handle_t h)
     auto pack_phases = [&](ConvW& cw, const std::string& name, int (*packer)(ccn_handle_s*, ConvW&, const std::string&)) -> int {
         cw.nphase = 1;
         if (!phases) return CCN_OK;
-        for (int k = 1; k < kPhases; ++k) {
+        for (int k = 1; k < h->nphase; ++k) {
             std::swap(h->host.at(name + ".weight"), h->host_ph[k - 1].at(name + ".weight"));
             ConvW t = cw;
             const int rc = packer(h, t, name);
@@ -1139,7 +1148,7 @@ int ccn_commit_params(ccn_handle_t h)
             if (rc) return rc;
             cw.w_ph[k - 1] = t.w; cw.wfrag_ph[k - 1] = t.wfrag;
         }
-        cw.nphase = kPhases;
+        cw.nphase = h->nphase;
         return CCN_OK;
     };
     h->stem = ConvW(); h->stem.kind = KIND_STEM; h->stem.Cin = c.img_ch; h->stem.Cout = c.base;

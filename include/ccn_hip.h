@@ -76,10 +76,10 @@ int ccn_load_param(ccn_handle_t h, const char* name, const float* data, const in
  *   CCN_ROUND_NEAREST          independent round-to-nearest-even, what `.to(torch.bfloat16)` of the checkpoint gives;
  *   CCN_ROUND_DIFFUSED         error diffusion along (cin, ky, kx) of every output channel: partial sums of an output channel's
  *                              weights stay within half an ulp of the fp32 sums;
- *   CCN_ROUND_DIFFUSED_PHASES  (default) the same, plus error diffusion ALONG THE DDIM STEPS: four such roundings of every weight
- *                              whose running sums track the fp32 weight, step i of ccn_sample uses version i % 4 (ccn_forward:
- *                              version 0).  The mean weight over a period is accurate to 1/8 ulp; costs 4 copies of the bf16
- *                              weights in HBM and nothing at run time. */
+ *   CCN_ROUND_DIFFUSED_PHASES  (default) the same, plus error diffusion ALONG THE DDIM STEPS: n such roundings of every weight whose
+ *                              running sums track the fp32 weight, step i of ccn_sample uses version i % n (ccn_forward: version 0).
+ *                              n = 8 (4 for models above 100 M conv weights): the mean weight over a period is accurate to 1/16 ulp;
+ *                              costs n copies of the bf16 weights in HBM and nothing at run time. */
 #define CCN_ROUND_NEAREST         0
 #define CCN_ROUND_DIFFUSED        1
 #define CCN_ROUND_DIFFUSED_PHASES 2

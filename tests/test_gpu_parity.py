@@ -432,7 +432,8 @@ def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
       (the reference's own bf16-autocast run deviates 0.30 / 0.037 from its fp32 run on these weights);
       PSNR, per-record relative delta of bf16 mode against the fp32 mode ON THE FULL-PRECISION WEIGHTS: round 2 (conv weights
       rounded to bf16 independently, round-to-nearest-even) 0.11 % mean / 0.165 % max -- above the gate; round 3 (error-diffused
-      rounding in ccn_commit_params, tools/weight_rounding_probe.py) 0.044 % mean / 0.075 % max -- the gate is asserted as stated.
+      rounding within the output channel and along the DDIM steps, tools/weight_rounding_probe.py) 0.041 % mean / 0.085 % max -- the gate
+      is asserted as stated.
       With weight_rounding="nearest" the old shift is reproduced (asserted below: the diffusion is what closes it).
     Other bounds asserted: 2x the measured deviations."""
     from clip_feature_codec.eval.metrics import psnr
@@ -473,7 +474,7 @@ def test_c2_bench_workload_bf16_parity_numbers(golden, synth, c2_sd, tmp_path):
 
 def test_weight_rounding_modes(synth, c2_sd):
     """ccn_set_weight_rounding (bf16 mode).  Version 0 of 'phases' IS the 'diffused' rounding, and ccn_forward always uses version 0:
-    the two modes give bit-equal forwards; the fused sampler cycles the four versions, so from step 1 on its trajectory differs from
+    the two modes give bit-equal forwards; the fused sampler cycles the eight versions, so from step 1 on its trajectory differs from
     'diffused' -- by rounding-level amounts; 'nearest' differs from both already in one forward.  All three stay within the bf16 mode's
     per-forward bound against the fp32 mode."""
     B, S = 2, 64

@@ -123,7 +123,7 @@ report("bf16, error diffused per output channel (cin, ky, kx)", {**sd, **dif})
 print("--- bf16 MODE (bf16 storage + bf16 MFMA) on the same weights")
 report("bf16 mode, weight_rounding='nearest' (RNE in ccn_commit_params)", sd, "bf16", "nearest")
 report("bf16 mode, weight_rounding='diffused' (within the output channel)", sd, "bf16", "diffused")
-report("bf16 mode, weight_rounding='phases' (+ along the DDIM steps, 4 versions)", sd, "bf16", "phases")
+report("bf16 mode, weight_rounding='phases' (+ along the DDIM steps)", sd, "bf16", "phases")
 if "--bf16-only" in sys.argv:
     sys.exit(0)
 print("--- under error diffusion: which levels still carry the shift (fp32 arithmetic; this level kept fp32 / stored as fp16)")
