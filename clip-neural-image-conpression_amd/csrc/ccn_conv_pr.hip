@@ -78,10 +78,13 @@ static_assert(PrLds::TOTAL <= 160 * 1024, "LDS budget");
 // fragments: twice the weight stream per MFMA of the 8-row form, still from L2).
 // GS: how the input's GroupNorm reaches the kernel -- 0 the finalized scale / shift table (a.gn_ab), 1 formed here from the producer
 // kernel's partial sums (a.gs_part), 2 none (the input is already activated, or the form has no GroupNorm: ConvTranspose, stride 2).
-template <int NTAPS, int D, int MODE, int TH = 8, int GS = 0>
+// P4 (NTAPS == 4 only): the 4x4 stride-2 pad-1 convolution (the data gradient of the ConvTranspose, training) as FOUR plane passes per
+// channel chunk with 2x2 taps each -- the ConvTranspose form's consumers on the stride-2 form's staging; see the pass table below.
+template <int NTAPS, int D, int MODE, int TH = 8, int GS = 0, bool P4 = false>
 __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const int grid_tiles)
 {
     static_assert(TH == 8 || (TH == 4 && NTAPS == 9), "4-row tiles: 3x3 stride-1 form only");
+    static_assert(!P4 || (NTAPS == 4 && MODE != 2), "plane passes of 2x2 taps: the 4-tap consumers, no split-K");
     constexpr bool RES = MODE == 1;                            // residual registers: MODE 1 always, MODE 2 in the second K half
     constexpr bool RR = MODE != 0;
     typedef __bf16 T;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     constexpr int HROWS = TH + 2;
     // output stride / parities of the form (launch_conv_pr checks a.OS / a.npar against them): compile-time, so the tile decodes and
     // the epilogue's address arithmetic fold for the 3x3 forms
-    constexpr int OSC = NTAPS == 4 ? 2 : 1, NPARC = NTAPS == 4 ? 4 : 1;
+    constexpr int OSC = (NTAPS == 4 && !P4) ? 2 : 1, NPARC = (NTAPS == 4 && !P4) ? 4 : 1;
     constexpr int EPC = 8, CKE = 64;
     constexpr int NSTEP = NTAPS * 4;                           // step = tap * 4 + kk (one 16-byte K slice per lane half)
     // NTAPS == 2: the stride-2 3x3 conv.  Its 9 taps fall on the four parity planes P[py][px](i, j) = in(2i+py, 2j+px) of the
@@ -100,8 +103,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     // channel chunk (plane (1,1) twice, the tenth tap slot has zero weights):
     //   pass 0: plane (1,1), taps (dy,dx) (0,0) (0,2) at offsets (-1,-1) (-1,0)      pass 1: plane (1,1), (2,0) (2,2) at (0,-1) (0,0)
     //   pass 2: plane (1,0), (0,1) (2,1) at (-1,0) (0,0)      pass 3: plane (0,1), (1,0) (1,2) at (0,-1) (0,0)      pass 4: plane (0,0), (1,1) at (0,0)
+    // P4: out(y,x) = sum over ky, kx = 0..3 of w[ky][kx] in(2y + ky - 1, 2x + kx - 1).  Row 2y + ky - 1 lies on plane py = 1 for
+    // ky = 0 (i = y - 1) and ky = 2 (i = y), on plane py = 0 for ky = 1 (i = y) and ky = 3 (i = y + 1); columns alike: every plane
+    // carries 2x2 taps at offsets (i - py, j - px), i, j = 0..1.  Pass p of a channel chunk stages plane (py, px) = (p < 2, !(p & 1)).
     constexpr bool S2 = NTAPS == 2;
-    constexpr int IS = S2 ? 2 : 1;                             // input stride of the staged plane
+    constexpr int NPASS = S2 ? 5 : (P4 ? 4 : 1);               // plane passes per channel chunk
+    constexpr int IS = (S2 || P4) ? 2 : 1;                     // input stride of the staged plane
     static_assert(NSTEP % D == 0, "the register ring must wrap at the chunk boundary");
     using L = PrLdsT<TH>;
     constexpr int HPITCH = L::HPITCH;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
             q_iy0 = ty * TH - 1; q_ix0 = tx * 32 - 1;
         }
         q_c = vt_kh(v) * nck + rq_c;
-        const int cb = (S2 ? q_c / 5 : q_c) * CKE + ck * EPC;
+        const int cb = (q_c / NPASS) * CKE + ck * EPC;
         q_cv = q_tv && cb < a.Cin;
         q_cbs = q_cv ? cb : 0;
         const bool fresh = gstat && rq_c == 0 && q_tv && q_b != st_b;  // wave-uniform: statistics of another sample needed
@@ -498,9 +505,10 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
     auto issue_loads = [&](int r0 = 0, int r1 = TH + 2, bool with_x = true) __attribute__((always_inline)) {
         // (readfirstlane: these are wave-uniform by construction; saying so keeps the descriptor in SGPRs)
         const int b = __builtin_amdgcn_readfirstlane(q_b), iy0 = __builtin_amdgcn_readfirstlane(q_iy0), ix0 = __builtin_amdgcn_readfirstlane(q_ix0);
-        const int cc = __builtin_amdgcn_readfirstlane(S2 ? q_c / 5 : q_c);     // channel chunk
-        const int pass = S2 ? q_c - cc * 5 : 0;
-        const int py = S2 ? (pass <= 2 ? 1 : 0) : 0, px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : 0;   // plane of this pass
+        const int cc = __builtin_amdgcn_readfirstlane(q_c / NPASS);           // channel chunk
+        const int pass = q_c - cc * NPASS;
+        const int py = S2 ? (pass <= 2 ? 1 : 0) : (P4 ? (pass < 2 ? 1 : 0) : 0);                          // plane of this pass
+        const int px = S2 ? ((pass <= 1 || pass == 3) ? 1 : 0) : (P4 ? ((pass & 1) ? 0 : 1) : 0);
         const int cb = cc * CKE + ck * EPC;
         const bool cv = q_tv && cb < a.Cin;
         q_cv_i = cv;
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
         const int v = vt(ti), v_next = ti + 1 < my_tiles ? vt(ti + 1) : v;
         const int tile = vt_tile(v), c0 = vt_kh(v) * nck;        // first chunk of this virtual tile
         int toffs[NTAPS], tdxs[NTAPS];                            // ConvTranspose: the parity's 2x2 taps (wave-uniform)
-        if constexpr (NTAPS == 4) {
+        if constexpr (NTAPS == 4 && !P4) {
             const int par = CCN_FDIV(tile, a.fd_nt, a.n_nt) % NPARC;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) { tdxs[t] = a.tapinfo_dx(par * 4 + t); toffs[t] = a.tapinfo_dy(par * 4 + t) * HPITCH + tdxs[t]; }
@@ -827,6 +835,12 @@ __global__ __launch_bounds__(512) void conv_pr_kernel(const ConvArgs a, const in
                 tdxs[0] = (pass == 0 || pass == 1 || pass == 3) ? -1 : 0; tdxs[1] = 0;
                 toffs[0] = ((pass == 0 || pass == 2) ? -HPITCH : 0) + tdxs[0];
                 toffs[1] = pass == 0 ? -HPITCH : 0;
+            }
+            if constexpr (P4) {                                    // this pass's 2x2 taps inside the staged plane
+                const int pass = (c0 + chunk) & 3;
+                const int py = pass < 2 ? 1 : 0, px = (pass & 1) ? 0 : 1;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) { tdxs[t] = (t & 1) - px; toffs[t] = ((t >> 1) - py) * HPITCH + tdxs[t]; }
             }
 #pragma unroll
             for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(prow[i]));    // keep the address math inside the loop
@@ -902,6 +916,7 @@ constexpr int PR_D = 6;                                          // weight ring 
 typedef void (*pr_fn_t)(const ConvArgs, int);
 static pr_fn_t pick_pr(int ntaps, int mode, int th = 8, int gs = 0)
 {
+    if (ntaps == 16) return mode == 1 ? (pr_fn_t)conv_pr_kernel<4, 8, 1, 8, 0, true> : (pr_fn_t)conv_pr_kernel<4, 8, 0, 8, 0, true>;   // 4x4 s2 as plane passes
     if (gs == 1 && ntaps == 9 && mode != 2) {
         if (th == 4) return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 4, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 4, 1>;
         return mode == 1 ? (pr_fn_t)conv_pr_kernel<9, PR_D, 1, 8, 1> : (pr_fn_t)conv_pr_kernel<9, PR_D, 0, 8, 1>;
@@ -925,8 +940,9 @@ static int g_cus = 0;
 hipError_t conv_pr_prepare()
 {
     hipError_t e = hipSuccess;
-    for (int ntaps : {2, 4, 9})
+    for (int ntaps : {2, 4, 9, 16})
         for (int mode = 0; mode < 3; ++mode) {
+            if (ntaps == 16 && mode == 2) continue;
             e = hipFuncSetAttribute((const void*)pick_pr(ntaps, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PrLds::TOTAL);
             if (e != hipSuccess) return e;
         }
@@ -972,8 +988,10 @@ hipError_t launch_conv_pr(int dtype, const ConvArgs& a, hipStream_t s)
     // a.ntaps as the persistent kernel sees the layer: 9 (3x3 s1), 4 (ConvTranspose parity), 2 (3x3 s2 as plane passes, nchunk = 5 x channel chunks)
     const bool c3 = a.ntaps == 9 && a.npar == 1 && a.OS == 1, ct = a.ntaps == 4 && a.npar == 4 && a.OS == 2;
     const bool s2 = a.ntaps == 2 && a.npar == 1 && a.OS == 1 && !a.gn_ab && (a.nchunk % 5) == 0;
-    if ((ct || s2) && (a.gn_ab || a.gs_part)) return hipErrorInvalidValue;     // (no input GroupNorm in those forms)
-    if (dtype != 1 || !a.wfrag || !(c3 || ct || s2) || !(a.th == 8 || (a.th == 4 && c3)) || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
+    // a.ntaps == 16: the 4x4 stride-2 conv as four plane passes of 2x2 taps (nchunk = 4 x channel chunks; training's ConvTranspose data gradient)
+    const bool p4 = a.ntaps == 16 && a.npar == 1 && a.OS == 1 && (a.nchunk % 4) == 0 && a.ksplit != 2;
+    if ((ct || s2 || p4) && (a.gn_ab || a.gs_part)) return hipErrorInvalidValue;     // (no input GroupNorm in those forms)
+    if (dtype != 1 || !a.wfrag || !(c3 || ct || s2 || p4) || !(a.th == 8 || (a.th == 4 && c3)) || (a.Cout_pad & 127) || a.nchunk < 2 || a.fin_counter || (a.res && a.film)) return hipErrorInvalidValue;
     const int ks = a.ksplit == 2 ? 2 : 1;
     if (ks == 2 && (!a.kpart || !a.kflag || (a.nchunk & 1) || (s2 && (a.nchunk / 2) % 5) || a.res)) return hipErrorInvalidValue;   // (split-K: MODE 2, no residual)
     const int ntiles = a.B * a.n_ty * a.n_tx * a.npar * a.n_nt * ks;

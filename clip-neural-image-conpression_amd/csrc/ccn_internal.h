@@ -41,6 +41,51 @@ __host__ __device__ inline size_t pr3_frag_index(int n, int k, int t, int Np)
     return ((((size_t)chunk * (size_t)(Np >> 5) + nn) * 36 + f) * 64 + lane) * 8 + e;
 }
 
+// ---- weight fragment order of the persistent kernel's 4x2-fragment forms (v_mfma_f32_32x32x16_bf16) ---------------------------
+// A 1-KiB fragment covers 32 output channels x one 16-byte K slice per lane half: lane l holds output channel (l & 31) of its
+// 32-channel column and input channels (2 kk + (l >> 5)) * 8 .. + 7 of the 64-channel chunk; a step's four K slices kk follow each other.
+// `group` counts the (..., tap) prefix of the form's order:
+__host__ __device__ inline size_t pr4_frag_elem(size_t group, int n, int k)
+{
+    const int kw = k & 63;
+    return ((group * 4 + (size_t)(kw >> 4)) * 64 + (size_t)((((kw >> 3) & 1) << 5) | (n & 31))) * 8 + (size_t)(kw & 7);
+}
+// ConvTranspose 4x4 s2 p1: [output parity][chunk][Np / 32][tap 0..3]; tap t of parity par reads kernel element prct_tap(par, t)
+// (even outputs <- k in {1, 3}, odd <- {0, 2}; the same order as fill_taps)
+__host__ __device__ inline int prct_tap(int par, int t)
+{
+    const int ky = (par >> 1) ? ((t >> 1) ? 2 : 0) : ((t >> 1) ? 3 : 1), kx = (par & 1) ? ((t & 1) ? 2 : 0) : ((t & 1) ? 3 : 1);
+    return ky * 4 + kx;
+}
+__host__ __device__ inline size_t prct_frag_index(int par, int t, int n, int k, int Np, int nch)
+{
+    return pr4_frag_elem((((size_t)par * nch + (k >> 6)) * (size_t)(Np >> 5) + (n >> 5)) * 4 + t, n, k);
+}
+// 3x3 stride 2 as plane passes: [chunk][pass 0..4][Np / 32][slot 0..1]; slot -> tap (dy * 3 + dx) of the 3x3 kernel, -1 = the empty
+// tenth slot (pass table in ccn_conv_pr.hip)
+__host__ __device__ inline int prs2_tap(int pass, int slot)
+{
+    const int dy = pass == 0 ? 0 : (pass == 1 ? 2 : (pass == 2 ? (slot ? 2 : 0) : 1));
+    const int dx = pass == 2 ? 1 : (pass == 4 ? 1 : (slot ? 2 : 0));
+    return (pass == 4 && slot) ? -1 : dy * 3 + dx;
+}
+__host__ __device__ inline size_t prs2_frag_index(int pass, int slot, int n, int k, int Np)
+{
+    return pr4_frag_elem((((size_t)(k >> 6) * 5 + pass) * (size_t)(Np >> 5) + (n >> 5)) * 2 + slot, n, k);
+}
+// 4x4 stride 2 pad 1 as plane passes (the ConvTranspose's data gradient): [chunk][pass 0..3][Np / 32][tap 0..3]; pass p stages input
+// plane (py, px) = (p < 2, !(p & 1)), tap t = (i, j) of it is kernel element (ky, kx) at plane offset (i - py, j - px)
+__host__ __device__ inline int prp4_tap(int pass, int t)
+{
+    const int py = pass < 2 ? 1 : 0, px = (pass & 1) ? 0 : 1, i = t >> 1, j = t & 1;
+    const int ky = py ? (i ? 2 : 0) : (i ? 3 : 1), kx = px ? (j ? 2 : 0) : (j ? 3 : 1);
+    return ky * 4 + kx;
+}
+__host__ __device__ inline size_t prp4_frag_index(int pass, int t, int n, int k, int Np)
+{
+    return pr4_frag_elem((((size_t)(k >> 6) * 4 + pass) * (size_t)(Np >> 5) + (n >> 5)) * 4 + t, n, k);
+}
+
 // ---- implicit-GEMM convolution ------------------------------------------------------------------
 // One kernel family covers every contraction on the path (models/unet.py:55,63,75,79 and
 // models/blocks.py:34,36).  M-space = the pixel grid a block tiles (TH=4 x TW=32 pixels per block):

@@ -18,6 +18,10 @@ enum PackMode {
     PK_HEAD_DG = 6,   // Conv2d (img_ch, C, 3, 3)      -> data gradient through the im2col kernel: N = C, K = img_ch * 9, taps flipped
     PK_FRAG3 = 7,     // Conv2d 3x3 s1, bf16           -> MFMA fragment order of the persistent kernel (ccn_conv_pr.hip), forward operand
     PK_FRAG3_DG = 8,  // Conv2d 3x3 s1, bf16           -> the same order for the data-gradient operand (taps flipped, N = I, K = O)
+    PK_FRAG_S2 = 9,   // Conv2d 3x3 s2, bf16           -> plane-pass fragment order of the persistent kernel's stride-2 form (prs2_frag_index)
+    PK_FRAG_CT = 10,  // ConvTranspose2d 4x4 s2, bf16  -> parity / tap fragment order of its ConvTranspose form (prct_frag_index)
+    PK_FRAG_P4_DG = 12,  // ConvTranspose2d 4x4 s2, bf16 -> its data-gradient operand (a 4x4 s2 conv) as plane passes of 2x2 taps (prp4_frag_index; N = I, K = O)
+    PK_FRAG_CT_DG = 11,  // Conv2d 3x3 s2, bf16        -> its data-gradient operand in that order (4x4 taps, row / column 3 zero; N = I, K = O)
 };
 
 // all repacks of one step in ONE launch: descriptor table built once at create time (offsets into the flat parameter buffer)
@@ -37,7 +41,7 @@ hipError_t launch_gn_stats(const float2* part, int B, int G, int n_sp, int n_nt,
                            const float* gamma, const float* beta, float eps, float2* ab, float2* stats, hipStream_t s);
 
 struct GnBwdGeom { int nslb, pstep, ppb, nblk, zblocks; };
-GnBwdGeom gn_bwd_geom(int dtype, int HW, int C);
+GnBwdGeom gn_bwd_geom(int dtype, int B, int HW, int C);
 // pass 1: per (sample, pixel block, channel) sums of da and da * xhat, da = dA * silu'(a x + c) (or dA)
 hipError_t launch_gn_bwd_reduce(int dtype, const void* x, const void* dA, const float2* ab, const float2* stats, float2* part,
                                 int B, int HW, int C, int cpg, int G, int silu, hipStream_t s);

@@ -217,6 +217,18 @@ bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
             w.pf_d = {src, w.wd_frag, PK_FRAG3_DG, w.Cout, w.Cin, 9, w.dCout_pad, w.dCin_pad};
         }
     }
+    // stride-2 conv / ConvTranspose on the persistent kernel's plane-pass / parity forms (bf16, 128-wide N tiles, >= 2 Cin chunks):
+    // the forward operands, and the stride-2 conv's data gradient (a ConvTranspose with the 3x3 kernel zero-padded to 4x4)
+    if (tr->elem == 2 && (fkind == KIND_C3S2 || fkind == KIND_CT4) && w.BN == 128 && w.Cin_pad >= 128) {
+        const int slots = fkind == KIND_C3S2 ? 10 : 16;
+        if (!alloc_dev(tr, (size_t)slots * w.Cout_pad * w.Cin_pad * 2, &w.wf_frag, err)) return false;
+        w.pf_f = {src, w.wf_frag, fkind == KIND_C3S2 ? PK_FRAG_S2 : PK_FRAG_CT, w.Cout, w.Cin, slots, w.Cout_pad, w.Cin_pad};
+    }
+    if (tr->elem == 2 && (fkind == KIND_C3S2 || fkind == KIND_CT4) && w.dBN == 128 && w.dCin_pad >= 128) {
+        // (the ConvTranspose's data gradient: a 4x4 stride-2 conv, run as four plane passes of 2x2 taps)
+        if (!alloc_dev(tr, (size_t)16 * w.dCout_pad * w.dCin_pad * 2, &w.wd_frag, err)) return false;
+        w.pf_d = {src, w.wd_frag, fkind == KIND_C3S2 ? PK_FRAG_CT_DG : PK_FRAG_P4_DG, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad};
+    }
     return true;
 }
 
@@ -339,11 +351,18 @@ struct Walk {
         const Geom g = geom_of(kind, Hin, Win, four);
         const int cke = tr->elem == 2 ? 64 : 32;
         const int n_nt = Npad / BN;
-        const int th = conv_tile_rows(kind, BN, B, g.MH, g.MW, g.npar, n_nt);
-        // the persistent register-weight kernel (ccn_conv_pr.hip) where the inference plan would use it: 3x3 s1, bf16, 8-row tiles
-        static const bool no_pr = diag_env("CCN_TRAIN_NO_PR") != nullptr;     // A/B switch
-        const bool pr = !no_pr && kind == KIND_C3S1 && frag.dst && conv_pr_selected(tr->cfg.dtype, kind, BN, th) && Kpad / cke >= 2 && !(res && film) &&
-                        (double)B * g.Hout * g.Wout * N * tr->elem < 2.0e9;
+        int th = conv_tile_rows(kind, BN, B, g.MH, g.MW, g.npar, n_nt);
+        // the persistent register-weight kernel (ccn_conv_pr.hip) where the inference plan would use it: bf16, 3x3 s1 on 8- or 4-row tiles;
+        // stride-2 conv (plane passes) and ConvTranspose (parities) on 8-row tiles as soon as half the CUs get one
+        static const bool no_pr = diag_env("CCN_TRAIN_NO_PR") != nullptr;     // A/B switches
+        static const bool no_pr2 = diag_env("CCN_TRAIN_NO_PR_S2CT") != nullptr;
+        static const long pr2_min = diag_env("CCN_TRAIN_PR2_MIN") ? atol(diag_env("CCN_TRAIN_PR2_MIN")) : 64;
+        bool pr = false;
+        if (!no_pr && frag.dst && Kpad / cke >= 2 && !(res && film) && (double)B * g.Hout * g.Wout * N * tr->elem < 2.0e9) {
+            if (kind == KIND_C3S1) pr = conv_pr_selected(tr->cfg.dtype, kind, BN, th);
+            else if (!no_pr2 && !gn_ab && (kind == KIND_C3S2 || (kind == KIND_CT4 && !four)) && conv_pr_selected(tr->cfg.dtype, kind, BN, 8) &&
+                     (long)B * ceil_div(g.MH, 8) * ceil_div(g.MW, 32) * g.npar * n_nt >= pr2_min) { pr = true; th = 8; }
+        }
         if (!base) pack_list.push_back(pr ? frag : plain);      // measuring walk: this shape's repack list
         ConvArgs a{};
         a.in = in; a.w = plain.dst; a.wfrag = pr ? frag.dst : nullptr; a.use_pr = pr ? 1 : 0; a.bias = bias; a.out = out_p;
@@ -353,6 +372,10 @@ struct Walk {
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
         a.th = th; a.n_ty = ceil_div(g.MH, th); a.n_tx = ceil_div(g.MW, 32); a.n_nt = n_nt;
         a.nchunk = Kpad / cke;
+        if (pr && kind == KIND_C3S2) {                                     // plane passes (ccn_conv_pr.hip)
+            if (four) a.nchunk *= 4;                                       // 4x4: four passes of 2x2 taps (a.ntaps stays 16)
+            else { a.nchunk *= 5; a.ntaps = 2; }                           // 3x3: five passes of two tap slots
+        }
         a.silu = 1; a.ksplit = 1;
         a.G = groups_for(N); a.cpg = N / a.G;
         a.nslot = a.n_ty * a.n_tx * g.npar * n_nt;                        // (the persistent kernel too: one partial per tile)
@@ -360,6 +383,8 @@ struct Walk {
         a.bn = BN;
         a.fin_blocks = a.n_ty * a.n_tx * g.npar * n_nt;
         a.eps_out = eps_out;
+        // (measured and dropped: capping the data-gradient convs' persistent grid to the CUs the side stream's weight-gradient kernel
+        // leaves free -- 192 / 160 / 128 workgroups: 652-658 vs 663 images/s uncapped; docs/EXPERIMENTS.md R3.12)
         fill_taps(a.tapinfo, kind, four);
         if (want_part && out) {
             out->part = (float2*)take((size_t)B * a.G * a.nslot * sizeof(float2));
@@ -512,7 +537,7 @@ struct Walk {
     bool conv_wgrad(const TConvW& w, const TT& xin, const float2* gn_ab, const void* dy, int Hdy, int Wdy, bool bias_done = false)
     {
         if (!wgrad_generic(w.kind, xin.p, xin.H, xin.W, w.Cin, w.Cin, gn_ab, 1, dy, w.Cout, w.Cout, grad_or_null(w.pw))) return false;
-        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, Hdy * Wdy, w.Cout);
+        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, B, Hdy * Wdy, w.Cout);
         want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
         if (!launch || bias_done) return true;
         mark(TF_BIAS);
@@ -546,7 +571,7 @@ struct Walk {
                 int film_off, float* film_bias = nullptr)
     {
         const int G = groups_for(x.C), cpg = x.C / G, HW = x.H * x.W;
-        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, HW, x.C);
+        const GnBwdGeom gg = gn_bwd_geom(tr->cfg.dtype, B, HW, x.C);
         want(need.scr_gn, (size_t)B * gg.nblk * x.C * sizeof(float2));
         want(need.scr_film, (size_t)B * gg.nblk * x.C * sizeof(float2));
         const float* film_r = film_off >= 0 && film ? film + film_off : nullptr;
@@ -661,7 +686,7 @@ struct Walk {
                 case L_STEM: {
                     const TConvW& w = tr->stem;
                     // in_conv.weight: 1x1 weight gradient against the im2col of the image (27 of 32 columns)
-                    const GnBwdGeom gg = gn_bwd_geom(dt, H * W, w.Cout);
+                    const GnBwdGeom gg = gn_bwd_geom(dt, B, H * W, w.Cout);
                     want(need.scr_col, (size_t)B * gg.nblk * w.Cout * 4);
                     void* col = take((size_t)B * H * W * 32 * tr->elem);
                     if (launch) {

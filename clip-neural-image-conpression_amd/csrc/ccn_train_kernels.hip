@@ -112,6 +112,62 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
 #pragma unroll
                     for (int t = 0; t < 9; ++t) v[t] = p[8 - t]; }
                 break;
+            case PK_FRAG_S2:
+                if (n < O && k < I) { const float* p = w + ((size_t)n * I + k) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = p[t]; }
+                break;
+            case PK_FRAG_CT:
+                if (n < O && k < I) { const float* p = w + ((size_t)k * O + n) * 16;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = p[t]; }
+                break;
+            case PK_FRAG_P4_DG:
+                if (n < I && k < O) { const float* p = w + ((size_t)n * O + k) * 16;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = p[t]; }
+                break;
+            case PK_FRAG_CT_DG:
+                if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) v[t] = ((t >> 2) < 3 && (t & 3) < 3) ? p[(t >> 2) * 3 + (t & 3)] : 0.f; }
+                break;
+        }
+        if (d.mode == PK_FRAG_S2) {
+            // plane-pass order of the persistent kernel's stride-2 form (prs2_frag_index, ccn_internal.h; pack_conv3 in ccn_api.hip)
+#pragma unroll
+            for (int ps = 0; ps < 10; ++ps) {
+                const int tp = prs2_tap(ps >> 1, ps & 1);
+                float val = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) val = t == tp ? v[t] : val;
+                dst[prs2_frag_index(ps >> 1, ps & 1, n, k, Np)] = to_elem<T>(val);
+            }
+            continue;
+        }
+        if (d.mode == PK_FRAG_P4_DG) {
+            // plane passes of the 4x4 stride-2 form (prp4_frag_index)
+#pragma unroll
+            for (int pt = 0; pt < 16; ++pt) {
+                const int tp = prp4_tap(pt >> 2, pt & 3);
+                float val = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) val = t == tp ? v[t] : val;
+                dst[prp4_frag_index(pt >> 2, pt & 3, n, k, Np)] = to_elem<T>(val);
+            }
+            continue;
+        }
+        if (d.mode == PK_FRAG_CT || d.mode == PK_FRAG_CT_DG) {
+            // parity / tap order of its ConvTranspose form (prct_frag_index; pack_convT in ccn_api.hip)
+#pragma unroll
+            for (int pt = 0; pt < 16; ++pt) {
+                const int tp = prct_tap(pt >> 2, pt & 3);
+                float val = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) val = t == tp ? v[t] : val;
+                dst[prct_frag_index(pt >> 2, pt & 3, n, k, Np, Kp >> 6)] = to_elem<T>(val);
+            }
+            continue;
         }
         if (d.mode == PK_FRAG3 || d.mode == PK_FRAG3_DG) {
             // fragment order of the persistent kernel's 3x3 form (pr3_frag_index, ccn_internal.h; pack_conv3 in ccn_api.hip)
@@ -242,7 +298,7 @@ hipError_t launch_gn_stats(const float2* part, int B, int G, int n_sp, int n_nt,
 
 // ---- GroupNorm (+SiLU) backward -----------------------------------------------------------------------------------------
 // Thread -> a fixed slice of 8 channels (coefficients in registers) x a strided set of the block's pixels.
-GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
+GnBwdGeom gn_bwd_geom(int dtype, int B, int HW, int C)
 {
     (void)dtype;
     GnBwdGeom g{};
@@ -250,9 +306,13 @@ GnBwdGeom gn_bwd_geom(int dtype, int HW, int C)
     int nslb = nsl <= 256 ? nsl : 256;
     while (nsl % nslb) --nslb;                                   // largest divisor of nsl that fits a workgroup
     g.nslb = nslb; g.zblocks = nsl / nslb; g.pstep = 256 / nslb;
-    // pixels per workgroup: at least 256 workgroups per sample (the 32-pixel level would otherwise run on 8), at most 32 passes
-    int iters = HW / (g.pstep * 256);
-    static const int cap = diag_env("CCN_GNB_ITERS") ? atoi(diag_env("CCN_GNB_ITERS")) : 32;
+    // pixels per workgroup: ~512 workgroups per launch over the batch (two per CU: enough loads in flight for an HBM-bound pass, and
+    // every workgroup's fixed cost -- coefficient loads, the LDS reduction, its row of partial sums -- is paid half as often as with
+    // the 1024 of round 2: 684 vs 643 images/s on the training step, sweep in docs/EXPERIMENTS.md R3.12), at most 64 passes
+    static const int env_minblk = diag_env("CCN_GNB_MINBLK") ? atoi(diag_env("CCN_GNB_MINBLK")) : 0;
+    const int minblk = env_minblk > 0 ? env_minblk : (512 / (B > 0 ? B : 1) > 32 ? 512 / (B > 0 ? B : 1) : 32);
+    int iters = HW / (g.pstep * minblk);
+    static const int cap = diag_env("CCN_GNB_ITERS") ? atoi(diag_env("CCN_GNB_ITERS")) : 64;
     iters = iters < 1 ? 1 : (iters > cap ? cap : iters);
     g.ppb = g.pstep * iters;
     g.nblk = (HW + g.ppb - 1) / g.ppb;
@@ -324,7 +384,7 @@ hipError_t launch_gn_bwd_reduce(int dtype, const void* x, const void* dA, const 
                                 int C, int cpg, int G, int silu, hipStream_t s)
 {
     if (C % 8) return hipErrorInvalidValue;
-    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const GnBwdGeom g = gn_bwd_geom(dtype, B, HW, C);
     const dim3 grid(g.nblk, B, g.zblocks);
     if (dtype == 0) hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dA, ab, stats, part, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
     else hipLaunchKernelGGL(gn_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dA, ab, stats, part, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
@@ -453,7 +513,7 @@ hipError_t launch_gn_bwd_apply(int dtype, const void* x, const void* dA, const f
                                int cpg, int G, int silu, hipStream_t s)
 {
     if (C % 8) return hipErrorInvalidValue;
-    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const GnBwdGeom g = gn_bwd_geom(dtype, B, HW, C);
     const dim3 grid(g.nblk, B, g.zblocks);
     if (dtype == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dA, ab, stats, gstat, (const float*)addend, (float*)out, film, film_bstride, fpart, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
     else hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dA, ab, stats, gstat, (const __bf16*)addend, (__bf16*)out, film, film_bstride, fpart, HW, C, cpg, G, silu, g.nslb, g.pstep, g.ppb, g.nblk);
@@ -558,7 +618,7 @@ hipError_t launch_colsum_from_pairs(const float2* part, int rows, int C, float* 
 hipError_t launch_colsum(int dtype, const void* dy, float* scratch, float* db, int B, int HW, int C, hipStream_t s)
 {
     if (C % 8) return hipErrorInvalidValue;
-    const GnBwdGeom g = gn_bwd_geom(dtype, HW, C);
+    const GnBwdGeom g = gn_bwd_geom(dtype, B, HW, C);
     const dim3 grid(g.nblk, B, g.zblocks);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);
     else hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, scratch, HW, C, g.nslb, g.pstep, g.ppb, g.nblk);

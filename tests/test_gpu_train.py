@@ -286,6 +286,42 @@ def test_bf16_step_on_the_persistent_kernel_with_ragged_tiles():
     print(f"bf16 on the persistent kernel, ragged tiles: worst cosine {worst[1]:.4f} ({worst[0]})")
 
 
+@pytest.mark.parametrize("ch_mult,B,H,W", [((1, 2), 4, 136, 200), ((1, 2, 2), 4, 256, 256)])
+def test_stride2_and_convtranspose_steps_on_the_persistent_kernel_match_the_generic_kernels(ch_mult, B, H, W):
+    """Round 3: with >= 128 eight-row tiles the bf16 step runs its stride-2 convs (five plane passes), its ConvTransposes (four
+    parities) and BOTH data gradients -- the stride-2 conv's (a ConvTranspose with the 3x3 kernel padded to 4x4) and the
+    ConvTranspose's (a 4x4 stride-2 conv as four plane passes of 2x2 taps, the P4 form) -- on the persistent kernel, from fragment
+    operands packed on the device (prs2 / prct / prp4_frag_index).  Same bf16 mode with the persistent kernel switched off (variant 3:
+    generic implicit-GEMM / free-running kernels, the [tap][N][K] operands): eps and every gradient must agree to bf16 noise --
+    a wrong tap, plane or fragment slot is an O(1) error.  Ragged tiles in the first case, the C5 per-GPU shape in the second."""
+    import ctypes
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, ch_mult))
+    g = torch.Generator("cpu").manual_seed(77)
+    x_t = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B))
+    t = torch.tensor([5, 250, 600, 990]); target = torch.randn((B, 3, H, W), generator=g)
+    lib = _native.load_library()
+    lib.ccn_internal_set_conv_variant.restype = ctypes.c_int
+    lib.ccn_internal_set_conv_variant.argtypes = [ctypes.c_int]
+    old = lib.ccn_internal_set_conv_variant(3)
+    try:
+        l3, g3, e3 = grads_via_autograd(make_net(sd, 128, ch_mult, dtype="bf16"), x_t, z, t, target)
+        lib.ccn_internal_set_conv_variant(4)
+        l4, g4, e4 = grads_via_autograd(make_net(sd, 128, ch_mult, dtype="bf16"), x_t, z, t, target)
+    finally:
+        lib.ccn_internal_set_conv_variant(old)
+    assert float((e4 - e3).abs().max()) < 4e-2, float((e4 - e3).abs().max())
+    assert float((e4 - e3).abs().mean()) < 2e-3, float((e4 - e3).abs().mean())
+    worst = ("", 0.0)
+    for k, r in g3.items():
+        a = g4[k].double().flatten(); b = r.double().flatten()
+        e = float((a - b).norm() / (b.norm() + 1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 0.08, (k, e)
+    print(f"persistent vs generic kernels, bf16 step {ch_mult} {B}x{H}x{W}: eps max diff {float((e4 - e3).abs().max()):.2e}, "
+          f"worst gradient relative L2 difference {worst[1]:.3e} ({worst[0]})")
+
+
 def test_c4_architecture_gradients_fp32():
     """BASELINE configs[3]'s architecture (base 192, (1,2,2,4): 24/48/96/384 channels per group, 3072-channel bottleneck whose
     GroupNorm passes span several channel blocks and which the pre-pass kernel cannot take) at 32 px, batch 1: every gradient
