@@ -20,12 +20,14 @@ enum PackMode {
     PK_FRAG3_DG = 8,  // Conv2d 3x3 s1, bf16           -> the same order for the data-gradient operand (taps flipped, N = I, K = O)
     PK_FRAG_S2 = 9,   // Conv2d 3x3 s2, bf16           -> plane-pass fragment order of the persistent kernel's stride-2 form (prs2_frag_index)
     PK_FRAG_CT = 10,  // ConvTranspose2d 4x4 s2, bf16  -> parity / tap fragment order of its ConvTranspose form (prct_frag_index)
+    PK_FRAG_STEM = 13,   // Conv2d (O, img_ch, 3, 3) + bias, bf16 -> register-fragment order of the stem kernel (ccn_stem.hip; bias as k = img_ch * 9)
+    PK_FRAG_STEM_HEAD_DG = 14,  // Conv2d (img_ch, C, 3, 3), bf16 -> the head's data gradient as a stem conv on d eps: N = C, k = co * 9 + tap, taps flipped
     PK_FRAG_P4_DG = 12,  // ConvTranspose2d 4x4 s2, bf16 -> its data-gradient operand (a 4x4 s2 conv) as plane passes of 2x2 taps (prp4_frag_index; N = I, K = O)
     PK_FRAG_CT_DG = 11,  // Conv2d 3x3 s2, bf16        -> its data-gradient operand in that order (4x4 taps, row / column 3 zero; N = I, K = O)
 };
 
 // all repacks of one step in ONE launch: descriptor table built once at create time (offsets into the flat parameter buffer)
-struct PackDesc { long long src_off; void* dst; int mode, O, I, taps, Np, Kp; };
+struct PackDesc { long long src_off; void* dst; int mode, O, I, taps, Np, Kp; long long aux_off; };   // aux_off: the bias (PK_FRAG_STEM)
 hipError_t launch_pack_group(int dtype, const float* params, const PackDesc* descs_dev, int n, hipStream_t s);
 
 // the FiLM linears of every ResBlock (to_scale / to_shift: models/blocks.py:19-20) share their input h: one launch each for the

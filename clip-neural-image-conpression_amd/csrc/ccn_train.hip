@@ -189,7 +189,14 @@ bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
         case KIND_STEM: w.pd_f = {src, w.wf, PK_STEM, w.Cout, w.Cin, 1, w.Cout_pad, w.Cin_pad}; break;
         default: w.pd_f = {src, w.wf, PK_CONV3, w.Cout, w.Cin, 9, w.Cout_pad, w.Cin_pad}; break;
     }
-    if (fkind == KIND_STEM) return true;                     // the image needs no gradient
+    if (fkind == KIND_STEM) {
+        // bf16: the register-weight stem kernel (ccn_stem.hip) instead of the generic one on an im2col tile
+        if (stem2_supported(tr->cfg.dtype, w.Cin, w.Cout, tr->G)) {
+            if (!alloc_dev(tr, (size_t)w.Cout * 32 * 2, &w.wf_frag, err)) return false;
+            w.pf_f = {src, w.wf_frag, PK_FRAG_STEM, w.Cout, w.Cin, 1, w.Cout, 32, (long long)tr->params[w.pb].off};
+        }
+        return true;                                         // the image needs no gradient
+    }
     // data gradient: a convolution from Cout back to Cin
     switch (fkind) {
         case KIND_C3S1: w.dkind = KIND_C3S1; w.dtaps = 9; break;
@@ -206,6 +213,11 @@ bool setup_conv(ccn_trainer_s* tr, TConvW& w, std::string& err)
         case KIND_C3S2: w.pd_d = {src, w.wd, PK_DG3S2, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad}; break;
         case KIND_CT4: w.pd_d = {src, w.wd, PK_DGT, w.Cout, w.Cin, 16, w.dCout_pad, w.dCin_pad}; break;
         case KIND_HEAD: w.pd_d = {src, w.wd, PK_HEAD_DG, w.Cout, w.Cin, 1, w.dCout_pad, w.dCin_pad}; break;
+    }
+    if (fkind == KIND_HEAD && stem2_supported(tr->cfg.dtype, w.Cout, w.Cin, tr->G)) {
+        // the head's data gradient is a stem conv (img_ch -> C, taps flipped) on d eps, which arrives as NCHW fp32 like the image
+        if (!alloc_dev(tr, (size_t)w.Cin * 32 * 2, &w.wd_frag, err)) return false;
+        w.pf_d = {src, w.wd_frag, PK_FRAG_STEM_HEAD_DG, w.Cout, w.Cin, 1, w.Cin, 32, 0};
     }
     if (fkind == KIND_C3S1 && tr->elem == 2) {
         if (w.BN == 128 && w.Cin_pad >= 128) {
@@ -363,7 +375,9 @@ struct Walk {
             else if (!no_pr2 && !gn_ab && (kind == KIND_C3S2 || (kind == KIND_CT4 && !four)) && conv_pr_selected(tr->cfg.dtype, kind, BN, 8) &&
                      (long)B * ceil_div(g.MH, 8) * ceil_div(g.MW, 32) * g.npar * n_nt >= pr2_min) { pr = true; th = 8; }
         }
-        if (!base) pack_list.push_back(pr ? frag : plain);      // measuring walk: this shape's repack list
+        static const bool no_stem2 = diag_env("CCN_TRAIN_NO_STEM2") != nullptr;
+        const bool stem2 = !no_stem2 && kind == KIND_STEM && frag.dst && stem2_supported(tr->cfg.dtype, K, N, tr->G) && !gn_ab && !film && !res;
+        if (!base) pack_list.push_back((pr || stem2) ? frag : plain);      // measuring walk: this shape's repack list
         ConvArgs a{};
         a.in = in; a.w = plain.dst; a.wfrag = pr ? frag.dst : nullptr; a.use_pr = pr ? 1 : 0; a.bias = bias; a.out = out_p;
         a.gn_ab = gn_ab; a.film = film; a.res = res;
@@ -379,6 +393,7 @@ struct Walk {
         a.silu = 1; a.ksplit = 1;
         a.G = groups_for(N); a.cpg = N / a.G;
         a.nslot = a.n_ty * a.n_tx * g.npar * n_nt;                        // (the persistent kernel too: one partial per tile)
+        if (stem2) { a.use_stem2 = 1; a.wfrag = frag.dst; a.nslot = 4 * stem2_blocks(Hin, Win, nullptr); }   // one slot per wave
         a.film_bstride = tr->F;
         a.bn = BN;
         a.fin_blocks = a.n_ty * a.n_tx * g.npar * n_nt;
@@ -389,6 +404,7 @@ struct Walk {
         if (want_part && out) {
             out->part = (float2*)take((size_t)B * a.G * a.nslot * sizeof(float2));
             out->n_sp = a.n_ty * a.n_tx * g.npar; out->n_nt = n_nt; out->bn = BN;
+            if (stem2) { out->n_sp = a.nslot; out->n_nt = 1; out->bn = 1 << 30; }
             a.part = out->part;
         }
         if (!launch) return true;

@@ -61,6 +61,18 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
     T* dst = (T*)d.dst;
     const int O = d.O, I = d.I, Np = d.Np, Kp = d.Kp;
     const size_t plane = (size_t)Np * Kp;
+    if (d.mode == PK_FRAG_STEM || d.mode == PK_FRAG_STEM_HEAD_DG) {
+        // ccn_stem.hip's order: [N / 32][k-step 2][lane = h * 32 + r][8]: lane (r, h) holds output channel j * 32 + r, k = 16 s + 8 h + e
+        const int N = d.mode == PK_FRAG_STEM ? O : I, K = (d.mode == PK_FRAG_STEM ? I : O) * 9;
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)N * 32; idx += (size_t)gridDim.x * blockDim.x) {
+            const int k = (int)(idx & 31), n = (int)(idx >> 5);
+            float v = 0.f;
+            if (d.mode == PK_FRAG_STEM) v = k < K ? w[(size_t)n * K + k] : (k == K ? params[d.aux_off + n] : 0.f);
+            else if (k < K) { const int co = k / 9, tp = k - co * 9; v = w[((size_t)co * I + n) * 9 + (8 - tp)]; }
+            dst[((((size_t)(n >> 5) * 2 + (k >> 4)) * 64) + (size_t)((((k >> 3) & 1) << 5) | (n & 31))) * 8 + (k & 7)] = to_elem<T>(v);
+        }
+        return;
+    }
     if (d.mode == PK_STEM || d.mode == PK_HEAD_DG) {
         for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
             const int k = (int)(idx % Kp), n = (int)(idx / Kp);
@@ -1322,10 +1334,14 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
 }
 __global__ void mse_final_kernel(const float* __restrict__ scratch, int nb, double inv_n, float* __restrict__ loss)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    // one wave, fixed order: lane l sums partials l, l + 64, ... in fp64, then a shuffle tree (a single thread walking the 1024 partials
+    // took 46 us between the forward and the backward of the step)
+    if (blockIdx.x) return;
     double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += (double)scratch[i];
-    *loss = (float)(s * inv_n);
+    for (int i = (int)threadIdx.x; i < nb; i += 64) s += (double)scratch[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (threadIdx.x == 0) *loss = (float)(s * inv_n);
 }
 hipError_t launch_mse_loss_grad(const float* eps, const float* target, int64_t n, float* loss, float* d_eps, float* scratch, hipStream_t s)
 {
