@@ -89,3 +89,67 @@ def test_every_fragment_read_is_bank_conflict_free():
         return (hh * HPITCH + hx) * 128 + (((g + 4 * k32) ^ ((hx >> 1) & 7)) & 7) * 16
     worst = max(16 - len({(old(l, 1, 0, 0, 0) // 16) % 16 for l in grp}) for grp in groups)
     assert worst > 0
+
+
+# ---- 4x2-fragment forms (v_mfma_f32_32x32x16_bf16): ConvTranspose parities, stride-2 plane passes, 4x4 stride-2 plane passes --------
+# restated from ccn_internal.h (pr4_frag_elem, prct_* / prs2_* / prp4_*); the host packers (ccn_api.hip) and the device packers of the
+# training step (ccn_train_kernels.hip) both go through those functions, and the GPU tests pin the kernels that read the buffers
+
+def pr4_frag_elem(group, n, k):
+    kw = k & 63
+    return ((group * 4 + (kw >> 4)) * 64 + ((((kw >> 3) & 1) << 5) | (n & 31))) * 8 + (kw & 7)
+
+
+def prct_tap(par, t):
+    ky = ((2 if (t >> 1) else 0) if (par >> 1) else (3 if (t >> 1) else 1))
+    kx = ((2 if (t & 1) else 0) if (par & 1) else (3 if (t & 1) else 1))
+    return ky * 4 + kx
+
+
+def prs2_tap(p, s):
+    dy = 0 if p == 0 else (2 if p == 1 else ((2 if s else 0) if p == 2 else 1))
+    dx = 1 if p in (2, 4) else (2 if s else 0)
+    return -1 if (p == 4 and s) else dy * 3 + dx
+
+
+def prp4_tap(p, t):
+    py, px, i, j = (1 if p < 2 else 0), (0 if (p & 1) else 1), t >> 1, t & 1
+    ky = ((2 if i else 0) if py else (3 if i else 1))
+    kx = ((2 if j else 0) if px else (3 if j else 1))
+    return ky * 4 + kx
+
+
+def test_tap_tables_of_the_plane_and_parity_forms_cover_every_kernel_element_once():
+    assert sorted(prct_tap(par, t) for par in range(4) for t in range(4)) == list(range(16))
+    assert sorted(prp4_tap(p, t) for p in range(4) for t in range(4)) == list(range(16))
+    slots = [prs2_tap(p, s) for p in range(5) for s in range(2)]
+    assert sorted(x for x in slots if x >= 0) == list(range(9)) and slots.count(-1) == 1
+
+
+def test_convtranspose_parity_taps_and_p4_plane_taps_are_the_same_geometry_read_both_ways():
+    """ConvTranspose2d(4, 2, 1): out = 2 in - 1 + k.  Output parity py reads k in {1, 3} (even) / {0, 2} (odd) at input offsets
+    {0, -1} / {+1, 0} (fill_taps); its data gradient, the 4x4 stride-2 pad-1 conv in(2y + k - 1), finds row 2y + k - 1 on input plane
+    py = (k - 1) & 1 at plane index y + (k - 1 - py) / 2 -- the P4 form's offsets (i - py)."""
+    for par in range(4):
+        for t in range(4):
+            ky, kx = divmod(prct_tap(par, t), 4)
+            for k, p in ((ky, par >> 1), (kx, par & 1)):
+                assert (k - 1) % 2 == p                # out = 2 in - 1 + k has parity p: k odd for even outputs
+    for p in range(4):
+        py, px = (1 if p < 2 else 0), (0 if (p & 1) else 1)
+        for t in range(4):
+            ky, kx = divmod(prp4_tap(p, t), 4)
+            i, j = t >> 1, t & 1
+            assert (ky - 1) % 2 == py and (ky - 1 - py) // 2 == i - py
+            assert (kx - 1) % 2 == px and (kx - 1 - px) // 2 == j - px
+
+
+def test_fragment_orders_of_the_4x2_forms_are_bijections():
+    O, I = 128, 128
+    n32, nch = O // 32, I // 64
+    ct = {pr4_frag_elem(((par * nch + (k >> 6)) * n32 + (n >> 5)) * 4 + t, n, k) for par in range(4) for t in range(4) for n in range(O) for k in range(I)}
+    assert len(ct) == 16 * O * I and max(ct) == 16 * O * I - 1
+    s2 = {pr4_frag_elem((((k >> 6) * 5 + p) * n32 + (n >> 5)) * 2 + s, n, k) for p in range(5) for s in range(2) for n in range(O) for k in range(I)}
+    assert len(s2) == 10 * O * I and max(s2) == 10 * O * I - 1
+    p4 = {pr4_frag_elem((((k >> 6) * 4 + p) * n32 + (n >> 5)) * 4 + t, n, k) for p in range(4) for t in range(4) for n in range(O) for k in range(I)}
+    assert len(p4) == 16 * O * I and max(p4) == 16 * O * I - 1
