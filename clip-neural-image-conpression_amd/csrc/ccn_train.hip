@@ -66,7 +66,7 @@ const char* kTrainFamilies[TF_COUNT] = {"weight_repack", "conditioning_fwd_bwd",
                                         "weight_grad_reduce", "bias_grad", "groupnorm_silu_film_bwd", "stem_head_weight_grad"};
 struct Mark { int fam; hipEvent_t ev; double flops, bytes; };
 
-struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; PackDesc* packs = nullptr; int n_packs = 0; };
+struct ShapeInfo { size_t scr_wg = 0, scr_gn = 0, scr_film = 0, scr_col = 0, tensors = 0, total = 0; PackDesc* packs = nullptr; int n_packs = 0, n_packs_fwd = 0; };
 
 }  // namespace
 
@@ -89,6 +89,9 @@ struct ccn_trainer_s {
     hipStream_t cap_stream = nullptr;
     std::vector<TGraph> graphs;
     hipStream_t side = nullptr;           // weight gradients run here, beside the data-gradient chain (nothing downstream reads them)
+    hipEvent_t pack_dg_done = nullptr;    // the data-gradient operands' repack, enqueued on `side` by the last forward
+    bool pack_dg_pending = false;
+    hipEvent_t fwd_fork = nullptr;
     std::vector<hipEvent_t> sync_pool; size_t sync_used = 0;
     LinDesc* lin_descs = nullptr; int n_lin = 0, max_lin_n = 0;
     std::vector<void*> allocs;
@@ -318,7 +321,13 @@ struct Walk {
     hipStream_t wg_stream = nullptr;
     // bucketed backward: cb(user, lo, hi) as soon as the gradients of flat range [lo, hi) are complete in stream order on `st`
     ccn_grad_ready_cb bucket_cb = nullptr; void* bucket_user = nullptr; long long bucket_floats = 0, hi_pending = 0;
-    const PackDesc* shape_packs = nullptr; int n_shape_packs = 0;
+    const PackDesc* shape_packs = nullptr; int n_shape_packs = 0, n_shape_packs_fwd = 0;
+    hipEvent_t sync_event_fwd()
+    {
+        // (the forward call's own fork event: the pool is reset at the start of every backward call, after this event has done its work)
+        if (!tr->fwd_fork && hipEventCreateWithFlags(&tr->fwd_fork, hipEventDisableTiming) != hipSuccess) tr->fwd_fork = nullptr;
+        return tr->fwd_fork;
+    }
     bool side_active() const
     {
         static const bool off_ = diag_env("CCN_TRAIN_NO_SIDE_STREAM") != nullptr;
@@ -481,7 +490,20 @@ struct Walk {
     {
         if (launch) {
             mark(TF_PACK);
-            if (!ok(launch_pack_group(tr->cfg.dtype, P, shape_packs, n_shape_packs, st), "pack")) return false;
+            // The forward convs' operands now, on this stream; the data-gradient convs' operands (the other half of the 0.18 ms repack)
+            // on the side stream beside the forward pass -- the backward pass waits for them (pack_dg_done).  One launch under a graph
+            // capture (the side branch would have to rejoin inside the forward's graph) and while profiling.
+            static const bool no_split = diag_env("CCN_TRAIN_NO_PACK_SPLIT") != nullptr;     // A/B switch
+            const bool split = !no_split && side_active() && tr->pack_dg_done && !tr->use_graph && n_shape_packs_fwd > 0 && n_shape_packs_fwd < n_shape_packs;
+            if (!ok(launch_pack_group(tr->cfg.dtype, P, shape_packs, split ? n_shape_packs_fwd : n_shape_packs, st), "pack")) return false;
+            tr->pack_dg_pending = false;
+            if (split) {
+                hipEvent_t e = sync_event_fwd();
+                if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) { err = "stream fork failed"; return false; }
+                if (!ok(launch_pack_group(tr->cfg.dtype, P, shape_packs + n_shape_packs_fwd, n_shape_packs - n_shape_packs_fwd, tr->side), "pack")) return false;
+                if (hipEventRecord(tr->pack_dg_done, tr->side) != hipSuccess) { err = "event record failed"; return false; }
+                tr->pack_dg_pending = true;
+            }
         }
         if (!conditioning(z, t)) return false;
         TT x; std::vector<TT> skips;
@@ -633,6 +655,10 @@ struct Walk {
         dfilm = (float*)take((size_t)B * tr->F * 4); dh = (float*)take((size_t)B * td * 4);
         dt1 = (float*)take((size_t)B * td * 16); du0 = (float*)take((size_t)B * td * 16); duz = (float*)take((size_t)B * td * 4);
         hi_pending = (long long)tr->total;
+        if (launch && tr->pack_dg_pending) {                   // the data-gradient operands repacked beside the forward pass
+            if (hipStreamWaitEvent(st, tr->pack_dg_done, 0) != hipSuccess) { err = "stream wait failed"; return false; }
+            tr->pack_dg_pending = false;
+        }
         if (launch && bucket_cb && hipMemsetAsync(dh, 0, (size_t)B * td * 4, st) != hipSuccess) { err = "hipMemsetAsync failed"; return false; }
         TT g;                                                  // gradient w.r.t. the current tensor
         std::vector<void*> dskip;                              // gradients waiting at the skip connections (pushed by the up path)
@@ -762,8 +788,11 @@ int shape_info(ccn_trainer_s* tr, int B, int H, int W, ShapeInfo* out)
     auto it = tr->shapes.find(key);
     if (it != tr->shapes.end()) { *out = it->second; return CCN_OK; }
     Walk w(tr, B, H, W, nullptr, false, nullptr, nullptr, nullptr);
-    if (!w.forward(nullptr, nullptr, nullptr, nullptr) || !w.backward(nullptr, nullptr, nullptr)) return tfail(CCN_EINVAL, w.err);
+    if (!w.forward(nullptr, nullptr, nullptr, nullptr)) return tfail(CCN_EINVAL, w.err);
+    const int n_packs_fwd = (int)w.pack_list.size();            // the forward convs' operands come first in the list
+    if (!w.backward(nullptr, nullptr, nullptr)) return tfail(CCN_EINVAL, w.err);
     ShapeInfo si = w.need;
+    si.n_packs_fwd = n_packs_fwd;
     si.tensors = align_up(w.off, 256);
     si.total = si.tensors + align_up(si.scr_wg, 256) + align_up(si.scr_gn, 256) + align_up(si.scr_film, 256) + align_up(si.scr_col, 256) +
                5 * 256;
@@ -845,6 +874,7 @@ int ccn_train_create(const ccn_config_t* cfg, ccn_trainer_t* out)
     if (good && hipMemset(zb, 0, (size_t)(maxc + 256) * 4) != hipSuccess) { good = false; err = "hipMemset failed"; }
     if (good && (conv_prepare() != hipSuccess || wgrad_prepare() != hipSuccess)) { good = false; err = "kernel attribute setup failed"; }
     if (good && hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) { tr->side = nullptr; }
+    if (good && tr->side && hipEventCreateWithFlags(&tr->pack_dg_done, hipEventDisableTiming) != hipSuccess) { tr->pack_dg_done = nullptr; }
     if (good) {
         // descriptor tables of the grouped launches (offsets into the caller's flat buffers are fixed by the architecture)
         std::vector<LinDesc> ld;
@@ -873,6 +903,8 @@ int ccn_train_destroy(ccn_trainer_t tr)
     if (tr->cap_stream) (void)hipStreamDestroy(tr->cap_stream);
     for (hipEvent_t e : tr->sync_pool) (void)hipEventDestroy(e);
     if (tr->side) (void)hipStreamDestroy(tr->side);
+    if (tr->pack_dg_done) (void)hipEventDestroy(tr->pack_dg_done);
+    if (tr->fwd_fork) (void)hipEventDestroy(tr->fwd_fork);
     delete tr;
     return CCN_OK;
 }
@@ -918,7 +950,7 @@ int ccn_train_forward(ccn_trainer_t tr, const float* params_dev, const float* x_
     auto body = [&](hipStream_t st, std::string& err) {
         Walk w(tr, B, H, W, workspace_dev, true, st, params_dev, nullptr);
         w.place_scratch(si);
-        w.shape_packs = si.packs; w.n_shape_packs = si.n_packs;
+        w.shape_packs = si.packs; w.n_shape_packs = si.n_packs; w.n_shape_packs_fwd = si.n_packs_fwd;
         if (!w.forward(x_t_dev, z_dev, t_dev, eps_dev)) { err = w.err; return false; }
         w.mark(-1);
         return true;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void ab_of(const float* abf, int c, float& a, float& 
 // thread -> one (n, k) pair: its taps are contiguous in the reference layouts (9 or 16 floats), so the reads are whole
 // segments and the writes, one per tap plane, are coalesced across the threads' consecutive k
 template <typename T>
-__global__ void pack_group_kernel(const float* __restrict__ params, const PackDesc* __restrict__ descs)
+__global__ __launch_bounds__(256) void pack_group_kernel(const float* __restrict__ params, const PackDesc* __restrict__ descs)
 {
     const PackDesc d = descs[blockIdx.y];
     const float* w = params + d.src_off;
@@ -80,6 +80,67 @@ __global__ void pack_group_kernel(const float* __restrict__ params, const PackDe
             if (d.mode == PK_STEM) { if (n < O && k < I * 9) v = w[(size_t)n * I * 9 + k]; }
             else if (n < I && k < O * 9) { const int co = k / 9, tp = k - co * 9; v = w[((size_t)co * I + n) * 9 + (8 - tp)]; }
             dst[idx] = to_elem<T>(v);
+        }
+        return;
+    }
+    if (sizeof(T) == 2 && (d.mode == PK_FRAG3 || d.mode == PK_FRAG3_DG || d.mode == PK_FRAG_S2 || d.mode == PK_FRAG_CT || d.mode == PK_FRAG_CT_DG ||
+                           d.mode == PK_FRAG_P4_DG)) {
+        // fragment orders: thread -> (output channel n, eight consecutive input channels k0 .. k0 + 7) with n fastest -- the eight values of
+        // a (tap / pass) slot are one 16-byte piece of a fragment and the pieces of neighbouring n are neighbours, so every store
+        // instruction writes whole 1-KiB fragment rows (one thread per (n, k) wrote 2-byte elements in eight places per instruction)
+        const int K8 = Kp >> 3, mode = d.mode;
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)Np * K8; idx += (size_t)gridDim.x * blockDim.x) {
+            const int n = (int)(idx % Np), k0 = (int)(idx / Np) * 8;
+            float v[8][16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[e][t] = 0.f;
+                if (mode == PK_FRAG3 || mode == PK_FRAG_S2) {
+                    if (n < O && k < I) { const float* p = w + ((size_t)n * I + k) * 9;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) v[e][t] = p[t]; }
+                } else if (mode == PK_FRAG3_DG) {
+                    if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) v[e][t] = p[8 - t]; }
+                } else if (mode == PK_FRAG_CT) {
+                    if (n < O && k < I) { const float* p = w + ((size_t)k * O + n) * 16;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) v[e][t] = p[t]; }
+                } else if (mode == PK_FRAG_CT_DG) {
+                    if (n < I && k < O) { const float* p = w + ((size_t)k * I + n) * 9;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) v[e][(t / 3) * 4 + (t % 3)] = p[t]; }
+                } else {                                         // PK_FRAG_P4_DG
+                    if (n < I && k < O) { const float* p = w + ((size_t)n * O + k) * 16;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) v[e][t] = p[t]; }
+                }
+            }
+            auto piece = [&](int tp) __attribute__((always_inline)) -> u32x4 {     // slot <- kernel element tp (< 0: empty slot)
+                u32x4 r = {0u, 0u, 0u, 0u};
+                if (tp >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = pack_bf2(v[2 * q][tp], v[2 * q + 1][tp]);
+                }
+                return r;
+            };
+            unsigned short* const db = (unsigned short*)dst;
+            if (mode == PK_FRAG3 || mode == PK_FRAG3_DG) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) *(u32x4*)(db + pr3_frag_index(n, k0, t, Np)) = piece(t);
+            } else if (mode == PK_FRAG_S2) {
+#pragma unroll
+                for (int ps = 0; ps < 10; ++ps) *(u32x4*)(db + prs2_frag_index(ps >> 1, ps & 1, n, k0, Np)) = piece(prs2_tap(ps >> 1, ps & 1));
+            } else if (mode == PK_FRAG_P4_DG) {
+#pragma unroll
+                for (int pt = 0; pt < 16; ++pt) *(u32x4*)(db + prp4_frag_index(pt >> 2, pt & 3, n, k0, Np)) = piece(prp4_tap(pt >> 2, pt & 3));
+            } else {
+#pragma unroll
+                for (int pt = 0; pt < 16; ++pt) *(u32x4*)(db + prct_frag_index(pt >> 2, pt & 3, n, k0, Np, Kp >> 6)) = piece(prct_tap(pt >> 2, pt & 3));
+            }
         }
         return;
     }
