@@ -68,6 +68,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32, ctypes.POINTER(c_i32)]),
     "ccn_mse_loss_grad": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "ccn_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "ccn_adamw_step_zero_grad": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "ccn_last_error": (ctypes.c_char_p, []),
     "ccn_version": (ctypes.c_char_p, []),
 }
@@ -426,15 +427,16 @@ def mse_loss_grad(eps: torch.Tensor, target: torch.Tensor, want_grad: bool = Tru
 
 
 def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
-               eps: float, weight_decay: float, step: int) -> None:
-    """One torch.optim.AdamW update over flat fp32 buffers, in place."""
+               eps: float, weight_decay: float, step: int, zero_grad: bool = False) -> None:
+    """One torch.optim.AdamW update over flat fp32 buffers, in place; ``zero_grad``: the gradients are left at zero by the same pass."""
     lib = load_library()
     for name, tns in (("params", p), ("grads", g), ("exp_avg", m), ("exp_avg_sq", v)):
         if not (tns.is_cuda and tns.dtype == torch.float32 and tns.is_contiguous() and tns.numel() == p.numel()):
             raise ValueError(f"{name} must be a contiguous fp32 HIP tensor of {p.numel()} elements")
     with torch.cuda.device(p.device):
-        check(lib.ccn_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
-                                 float(beta2), float(eps), float(weight_decay), int(step), current_stream(p.device)))
+        fn = lib.ccn_adamw_step_zero_grad if zero_grad else lib.ccn_adamw_step
+        check(fn(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+                 float(beta2), float(eps), float(weight_decay), int(step), current_stream(p.device)))
 
 
 # ---- stateless ops --------------------------------------------------------------------------------

@@ -199,12 +199,15 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros_like(fp.flat)
         self.steps = 0
 
-    def step(self) -> None:
+    def step(self, zero_grad: bool = False) -> None:
+        """``zero_grad=True``: ``step()`` + ``zero_grad()`` as one pass over the buffers (``ccn_adamw_step_zero_grad``)."""
         fp = self.state.fp
         self.steps += 1
         _native.adamw_step(fp.flat, fp.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                           self.weight_decay, self.steps)
+                           self.weight_decay, self.steps, zero_grad=zero_grad)
         fp.flat[:1].add_(0)    # the kernel wrote behind torch's back: bump the (shared) version counter so that a stale forward is detected
+        if zero_grad:
+            fp.rebind_grads()
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.state.fp.grad.zero_()
@@ -262,8 +265,11 @@ def train_step(net, sch, opt, x0: torch.Tensor, z: torch.Tensor, t: Optional[tor
             w.wait()
     else:
         state.trainer.backward(fp.flat, fp.grad, sb["x_t"], sb["z"], d_eps)
-    opt.step()
-    opt.zero_grad()
+    if isinstance(opt, FusedAdamW):
+        opt.step(zero_grad=True)
+    else:
+        opt.step()
+        opt.zero_grad()
     return loss
 
 

@@ -102,6 +102,6 @@ hipError_t launch_add2(float* y, const float* a, const float* b, int64_t n, hipS
 hipError_t launch_mse_loss_grad(const float* eps, const float* target, int64_t n, float* loss, float* d_eps, float* scratch, hipStream_t s);
 // torch.optim.AdamW step (train/diffusion_train.py:105,138): decoupled weight decay, bias-corrected moments
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                        int step, hipStream_t s);
+                        int step, hipStream_t s, bool zero_grad = false);
 
 }  // namespace ccn

@@ -1061,4 +1061,13 @@ int ccn_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev
     return CCN_OK;
 }
 
+int ccn_adamw_step_zero_grad(float* params_dev, float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, void* stream)
+{
+    if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || n <= 0 || step <= 0) return tfail(CCN_EINVAL, "bad argument");
+    if (launch_adamw(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream, true) != hipSuccess)
+        return tfail(CCN_EHIP, "adamw launch failed");
+    return CCN_OK;
+}
+
 }  // extern "C"

@@ -1412,11 +1412,13 @@ hipError_t launch_mse_loss_grad(const float* eps, const float* target, int64_t n
     return hipGetLastError();
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+template <bool ZERO>
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                              float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
+        if (ZERO) g[i] = 0.f;
         float pi = p[i] * (1.0f - lr * wd);
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -1427,11 +1429,12 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                        hipStream_t s)
+                        hipStream_t s, bool zero_grad)
 {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
     const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    if (zero_grad) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid ? grid : 1), dim3(256), 0, s, p, (float*)g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    else hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid ? grid : 1), dim3(256), 0, s, p, (float*)g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
     return hipGetLastError();
 }
 

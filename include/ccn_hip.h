@@ -262,6 +262,10 @@ int ccn_mse_loss_grad(const float* eps_dev, const float* target_dev, int64_t n, 
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps). step >= 1. */
 int ccn_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* The same step followed by opt.zero_grad() (train/diffusion_train.py:138-139) in the same pass: every gradient is read once and
+ * its slot left at zero (one launch and one 4-byte write per parameter instead of a second pass over the buffer). */
+int ccn_adamw_step_zero_grad(float* params_dev, float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 const char* ccn_last_error(void);
 const char* ccn_version(void);

@@ -241,6 +241,13 @@ def test_mse_loss_grad_and_adamw_kernels_against_torch():
         opt.step()
         _native.adamw_step(pd, (gr * step).to(DEV), m, v, 3e-4, 0.9, 0.99, 1e-8, 0.05, step)
     assert float((pd.cpu() - pt.detach()).abs().max()) < 2e-6
+    # step + zero_grad in one pass (ccn_adamw_step_zero_grad): the same update, bit for bit, and the gradient buffer left at zero
+    pa = p.to(DEV).clone(); pb = pa.clone(); ma, va, mb, vb = (torch.zeros(n, device=DEV) for _ in range(4))
+    ga = (gr * 2).to(DEV); gb = ga.clone()
+    _native.adamw_step(pa, ga, ma, va, 3e-4, 0.9, 0.99, 1e-8, 0.05, 1)
+    _native.adamw_step(pb, gb, mb, vb, 3e-4, 0.9, 0.99, 1e-8, 0.05, 1, zero_grad=True)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(ga, (gr * 2).to(DEV)) and not gb.any()
 
 
 def test_train_diffusion_entry_point_on_a_synthetic_store(tmp_path):
