@@ -403,23 +403,16 @@ int pack_conv3(ccn_handle_s* h, ConvW& cw, const std::string& name)     // Conv2
     int rc = pack_and_upload(h, cw, 9, [&](int t, int o, int i) { return i < I ? w[((size_t)o * I + i) * 9 + t] : 0.f; });
     if (rc) return rc;
     if (cw.kind == KIND_C3S2 && cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
-        // plane-pass order for the persistent kernel (ccn_conv_pr.hip, NTAPS == 2): [channel chunk][pass 0..4][Cout_pad/32][tap slot 0..1]
-        // [kk][lane][8]; slot -> (dy, dx) of the 3x3 kernel, the tenth slot is zero
-        static const int tdy[5][2] = {{0, 0}, {2, 2}, {0, 2}, {1, 1}, {1, -1}}, tdx[5][2] = {{0, 2}, {0, 2}, {1, 1}, {0, 2}, {1, -1}};
+        // plane-pass order for the persistent kernel (ccn_conv_pr.hip, NTAPS == 2): prs2_frag_index / prs2_tap (ccn_internal.h), the tenth
+        // tap slot stays zero; the training step's device-side packer (PK_FRAG_S2) goes through the same functions
         const int nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32, O = cw.Cout;
         std::vector<uint16_t> fr((size_t)nch * 5 * n32 * 2 * 4 * 64 * 8, 0);
-        size_t p = 0;
-        for (int c = 0; c < nch; ++c)
-            for (int pass = 0; pass < 5; ++pass)
-                for (int nn = 0; nn < n32; ++nn)
-                    for (int t = 0; t < 2; ++t)
-                        for (int q = 0; q < 4; ++q)
-                            for (int ln = 0; ln < 64; ++ln)
-                                for (int e = 0; e < 8; ++e, ++p) {
-                                    const int o = nn * 32 + (ln & 31), i = c * cke + (2 * q + (ln >> 5)) * 8 + e;
-                                    const int dy = tdy[pass][t], dx = tdx[pass][t];
-                                    fr[p] = (dy >= 0 && o < O && i < I) ? f2bf_host(w[((size_t)o * I + i) * 9 + dy * 3 + dx]) : 0;
-                                }
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int ps = 0; ps < 10; ++ps) {
+                    const int tp = prs2_tap(ps >> 1, ps & 1);
+                    if (tp >= 0) fr[prs2_frag_index(ps >> 1, ps & 1, o, i, cw.Cout_pad)] = f2bf_host(w[((size_t)o * I + i) * 9 + tp]);
+                }
         if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
     }
     if (cw.kind == KIND_C3S1 && cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
@@ -442,23 +435,15 @@ int pack_convT(ccn_handle_s* h, ConvW& cw, const std::string& name)     // ConvT
     int rc = pack_and_upload(h, cw, 16, [&](int t, int o, int i) { return i < I ? w[((size_t)i * O + o) * 16 + t] : 0.f; });
     if (rc) return rc;
     if (cw.BN == 128 && h->cfg.dtype == CCN_DTYPE_BF16) {
-        // fragment order for ccn_conv_pr.hip: [parity][chunk][Cout_pad/32][tap 0..3][kk][lane][8]; tap order and kernel
-        // indices as in fill_taps (even outputs <- k in {1, 3}, odd <- {0, 2})
-        static const int kk2[2][2] = {{1, 3}, {0, 2}};
+        // fragment order for ccn_conv_pr.hip: [parity][chunk][Cout_pad/32][tap 0..3][kk][lane][8] = prct_frag_index, tap -> kernel
+        // element prct_tap (ccn_internal.h; the same order as fill_taps: even outputs <- k in {1, 3}, odd <- {0, 2}); the training
+        // step's device-side packer (PK_FRAG_CT) goes through the same functions
         const int nch = cw.Cin_pad / cke, n32 = cw.Cout_pad / 32;
         std::vector<uint16_t> fr((size_t)4 * nch * n32 * 4 * 4 * 64 * 8, 0);
-        size_t p = 0;
-        for (int par = 0; par < 4; ++par)
-            for (int c = 0; c < nch; ++c)
-                for (int nn = 0; nn < n32; ++nn)
-                    for (int t = 0; t < 4; ++t)
-                        for (int q = 0; q < 4; ++q)
-                            for (int ln = 0; ln < 64; ++ln)
-                                for (int e = 0; e < 8; ++e, ++p) {
-                                    const int o = nn * 32 + (ln & 31), i = c * cke + (2 * q + (ln >> 5)) * 8 + e;
-                                    const int wt = kk2[par >> 1][t >> 1] * 4 + kk2[par & 1][t & 1];
-                                    fr[p] = (o < O && i < I) ? f2bf_host(w[((size_t)i * O + o) * 16 + wt]) : 0;
-                                }
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int pt = 0; pt < 16; ++pt)
+                    fr[prct_frag_index(pt >> 2, pt & 3, o, i, cw.Cout_pad, nch)] = f2bf_host(w[((size_t)i * O + o) * 16 + prct_tap(pt >> 2, pt & 3)]);
         if ((rc = upload(h, fr.data(), fr.size() * 2, &cw.wfrag))) return rc;
     }
     return upload_f32(h, name + ".bias", &cw.bias);
