@@ -343,6 +343,11 @@ struct Walk {
         wg_stream = tr->side;
         return true;
     }
+    hipEvent_t sync_event()
+    {
+        if (tr->sync_used == tr->sync_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; tr->sync_pool.push_back(e); }
+        return tr->sync_pool[tr->sync_used++];
+    }
     bool join_side()
     {
         if (!tr->side || tr->sync_used == 0) return true;
@@ -366,8 +371,11 @@ struct Walk {
 
     // ---- forward pieces --------------------------------------------------------------------------------------------------
     // generic launch of the forward conv kernels.  `kind`: kernel family; N = output channels of this launch, K = input channels
+    // input GroupNorm formed inside the persistent kernel from the producer's partial sums (its GS = 1; the inference plan's in_kernel_stats)
+    struct GsIn { const float2* part; int n_sp, n_nt, bn, cpg; const float* gamma; const float* beta; double inv_count; };
     bool run_conv(int fam, int kind, bool four, const PackDesc& plain, const PackDesc& frag, int BN, int K, int Kpad, int N, int Npad, const float* bias,
-                  const void* in, int Hin, int Win, TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out)
+                  const void* in, int Hin, int Win, TT* out, void* out_p, const float2* gn_ab, const float* film, const void* res, bool want_part, float* eps_out,
+                  const GsIn* gs = nullptr, bool* gs_used = nullptr)
     {
         const Geom g = geom_of(kind, Hin, Win, four);
         const int cke = tr->elem == 2 ? 64 : 32;
@@ -390,6 +398,13 @@ struct Walk {
         ConvArgs a{};
         a.in = in; a.w = plain.dst; a.wfrag = pr ? frag.dst : nullptr; a.use_pr = pr ? 1 : 0; a.bias = bias; a.out = out_p;
         a.gn_ab = gn_ab; a.film = film; a.res = res;
+        if (gs_used) *gs_used = false;
+        if (gs && pr && kind == KIND_C3S1) {                    // (no split-K in the training step)
+            a.gn_ab = nullptr;
+            a.gs_part = gs->part; a.gs_gamma = gs->gamma; a.gs_beta = gs->beta; a.gs_inv_count = gs->inv_count;
+            a.gs_nsp = gs->n_sp; a.gs_nnt = gs->n_nt; a.gs_bn = gs->bn; a.gs_cpg = gs->cpg;
+            if (gs_used) *gs_used = true;
+        }
         a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = K; a.Cin_pad = Kpad;
         a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = N; a.Cout_pad = Npad;
         a.MH = g.MH; a.MW = g.MW; a.OS = g.OS; a.npar = g.npar; a.ntaps = g.ntaps;
@@ -421,10 +436,66 @@ struct Walk {
         return ok(launch_conv(tr->cfg.dtype, kind, BN, a, st), "conv");
     }
     bool conv_fwd(const TConvW& w, const TT& in, TT& out, const float2* gn_ab, const float* film, const TT* res, bool want_part, const void* in_override = nullptr,
-                  float* eps_out = nullptr)
+                  float* eps_out = nullptr, const GsIn* gs = nullptr, bool* gs_used = nullptr)
     {
         return run_conv(TF_CONV_FWD, w.kind, false, w.pd_f, w.pf_f, w.BN, w.Cin, w.Cin_pad, w.Cout, w.Cout_pad, launch ? par(w.pb) : nullptr, in_override ? in_override : in.p, in.H, in.W,
-                        &out, out.p, gn_ab, film, res ? res->p : nullptr, want_part, eps_out);
+                        &out, out.p, gn_ab, film, res ? res->p : nullptr, want_part, eps_out, gs, gs_used);
+    }
+    // ---- forward ResBlock conv with its GroupNorm + SiLU, side-stream form (bf16, plain stream launches) --------------------------------
+    // The conv transforms its raw input in its producer waves (the inference kernels' prologue: statistics formed in-kernel from the
+    // partial sums where they are few, else from the table of a 5-us statistics launch), so the pass that WRITES the activated tensor
+    // -- which only the weight-gradient kernel reads, in the backward pass -- leaves the forward's critical path: it runs on the side
+    // stream beside the convs (HBM-bound next to MFMA-bound).  The backward pass waits for pack_dg_done, recorded after the last of them.
+    bool fwd_side_used = false;
+    bool side_pre_ok() const
+    {
+        static const bool off_ = diag_env("CCN_TRAIN_NO_SIDE_PRE") != nullptr;       // A/B switch
+        return launch && !off_ && side_active() && !tr->use_graph && tr->pack_dg_done && tr->elem == 2;
+    }
+    bool in_kernel_stats_ok(const TT& t, int C) const
+    {
+        const int G = groups_for(C), cpg = C / G;
+        if (tr->elem != 2 || t.n_sp <= 0 || G != 8 || (cpg % 8) != 0) return false;
+        int nj = 1;
+        for (int g = 0; g < G; ++g) { const int n = ((g + 1) * cpg - 1) / t.bn - (g * cpg) / t.bn + 1; if (n > nj) nj = n; }
+        return (long)t.n_sp * nj <= 64;
+    }
+    // (allocation order of the pre-pass form, which the never-launching measuring / replay walks go through: activated tensor -- by the
+    // caller --, tables, conv output, the output's partial sums)
+    bool norm_conv_fwd_side(const TT& x, const TNorm& n, const TConvW& w, float2*& ab, float2*& stats, const TT& xa, TT& y, const float* film_r, const TT* res)
+    {
+        const int G = groups_for(x.C), cpg = x.C / G;
+        ab = (float2*)take((size_t)B * x.C * sizeof(float2));
+        stats = (float2*)take((size_t)B * G * sizeof(float2));
+        y = new_tensor(w.Cout, x.H, x.W);
+        const double count = (double)cpg * x.H * x.W;
+        auto fork = [&]() -> bool {
+            hipEvent_t e = sync_event();
+            if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) { err = "stream fork failed"; return false; }
+            fwd_side_used = true;
+            return true;
+        };
+        const int dt = tr->cfg.dtype;
+        if (launch && in_kernel_stats_ok(x, x.C)) {
+            // statistics in the conv itself; the side stream's pass writes the activated tensor AND the tables the backward pass reads
+            const GsIn gs{x.part, x.n_sp, x.n_nt, x.bn, cpg, par(n.pg), par(n.pb), 1.0 / count};
+            bool used = false;
+            if (!fork()) return false;
+            if (!ok(launch_gn_act_fused(dt, x.p, xa.p, B, x.H * x.W, x.C, x.part, G, x.n_sp, x.n_nt, x.bn, cpg, count, par(n.pg), par(n.pb), 1e-5f, tr->side, ab, stats),
+                    "gn_act_fused")) return false;
+            if (!conv_fwd(w, x, y, nullptr, film_r, res, true, nullptr, nullptr, &gs, &used)) return false;
+            if (used) return true;
+            // (the conv did not land on the persistent kernel: it ran WITHOUT its GroupNorm -- cannot happen for the shapes side_pre_ok()
+            // admits, checked here rather than assumed)
+            err = "internal: in-kernel statistics requested for a conv outside the persistent kernel";
+            return false;
+        }
+        if (launch) {
+            if (!ok(launch_gn_stats(x.part, B, G, x.n_sp, x.n_nt, x.bn, cpg, x.C, count, par(n.pg), par(n.pb), 1e-5f, ab, stats, st), "gn_stats")) return false;
+            if (!fork()) return false;
+            if (!ok(launch_gn_act(dt, x.p, ab, xa.p, B, x.H * x.W, x.C, tr->side), "gn_act")) return false;
+        }
+        return conv_fwd(w, x, y, ab, film_r, res, true);
     }
     // dX = conv'(dY): N = the forward conv's Cin
     bool conv_dgrad(const TConvW& w, const void* dy, int Hdy, int Wdy, void* dx, const void* res)
@@ -488,6 +559,7 @@ struct Walk {
 
     bool forward(const float* x_t, const float* z, const int64_t* t, float* eps)
     {
+        if (launch && eps) tr->sync_used = 0;                    // (fork events of this call; a wait keeps the record it saw when it was enqueued)
         if (launch) {
             mark(TF_PACK);
             // The forward convs' operands now, on this stream; the data-gradient convs' operands (the other half of the 0.18 ms repack)
@@ -525,6 +597,15 @@ struct Walk {
                     static const bool no_pre = diag_env("CCN_TRAIN_NO_PREACT") != nullptr;       // A/B switch
                     ResSave s; s.x = x;
                     s.pre = !no_pre && r.C / (tr->elem == 2 ? 8 : 4) <= 256;
+                    // (side form: same allocation sequence as the pre-pass form -- activated tensor, tables, conv output -- so the
+                    // measuring and replay walks, which never launch, need not know which one ran)
+                    const bool sidef = s.pre && side_pre_ok() && conv_pr_selected(tr->cfg.dtype, KIND_C3S1, r.c1.BN, 8) && r.c1.pf_f.dst && r.c1.Cin_pad / 64 >= 2;
+                    if (sidef) {
+                        s.xa = new_tensor(r.C, x.H, x.W);
+                        if (!norm_conv_fwd_side(x, r.n1, r.c1, s.ab1, s.st1, s.xa, s.y, film ? film + r.film_off : nullptr, nullptr)) return false;
+                        s.ya = new_tensor(r.C, x.H, x.W);
+                        if (!norm_conv_fwd_side(s.y, r.n2, r.c2, s.ab2, s.st2, s.ya, s.o, nullptr, &x)) return false;
+                    } else {
                     if (s.pre) { s.xa = new_tensor(r.C, x.H, x.W); if (!gn_fwd_preact(x, r.n1, s.ab1, s.st1, s.xa)) return false; }
                     else if (!gn_fwd(x, r.n1, s.ab1, s.st1)) return false;
                     s.y = new_tensor(r.C, x.H, x.W);
@@ -533,6 +614,7 @@ struct Walk {
                     else if (!gn_fwd(s.y, r.n2, s.ab2, s.st2)) return false;
                     s.o = new_tensor(r.C, x.H, x.W);
                     if (!conv_fwd(r.c2, s.pre ? s.ya : s.y, s.o, s.pre ? nullptr : s.ab2, nullptr, &x, true)) return false;
+                    }
                     rs.push_back(s);
                     x = s.o;
                     break;
@@ -564,6 +646,10 @@ struct Walk {
                     break;
                 }
             }
+        }
+        if (launch && fwd_side_used) {                           // everything this forward put on the side stream: the backward pass waits for it
+            if (hipEventRecord(tr->pack_dg_done, tr->side) != hipSuccess) { err = "event record failed"; return false; }
+            tr->pack_dg_pending = true;
         }
         return true;
     }
