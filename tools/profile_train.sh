@@ -5,7 +5,7 @@ R=${1:-rXX}; CMP=${2:-}; O=gpurun_out/prof_train_$R; mkdir -p $O
 export TMPDIR=/tmp
 python bench_train.py > $O/${R}_bench_train_bf16.json 2> $O/bench.err
 if [ -n "$CMP" ] && [ -d "$CMP" ]; then
-  CCN_HIP_LIB=$PWD/$CMP/clip-neural-image-conpression_amd/csrc/libccn_hip.so python bench_train.py --no-cpu-baseline > $O/${R}_bench_train_bf16_older_build_same_box.json 2>> $O/bench.err
+  (cd $CMP && python bench_train.py --no-cpu-baseline) > $O/${R}_bench_train_bf16_older_build_same_box.json 2>> $O/bench.err   # the worktree's own package + library
 fi
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/stats -- python3 $OLDPWD/bench_train.py --no-cpu-baseline --no-roofline > /dev/null 2>&1)
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_bench_train_bf16_kernel_stats.csv
