@@ -293,27 +293,29 @@ def test_bf16_step_on_the_persistent_kernel_with_ragged_tiles():
     print(f"bf16 on the persistent kernel, ragged tiles: worst cosine {worst[1]:.4f} ({worst[0]})")
 
 
-@pytest.mark.parametrize("ch_mult,B,H,W", [((1, 2), 4, 136, 200), ((1, 2, 2), 4, 256, 256)])
-def test_stride2_and_convtranspose_steps_on_the_persistent_kernel_match_the_generic_kernels(ch_mult, B, H, W):
+@pytest.mark.parametrize("base,ch_mult,B,H,W", [(128, (1, 2), 4, 136, 200), (128, (1, 2, 2), 4, 256, 256), (192, (1, 2, 2, 4), 2, 128, 128)])
+def test_stride2_and_convtranspose_steps_on_the_persistent_kernel_match_the_generic_kernels(base, ch_mult, B, H, W):
     """Round 3: with >= 128 eight-row tiles the bf16 step runs its stride-2 convs (five plane passes), its ConvTransposes (four
     parities) and BOTH data gradients -- the stride-2 conv's (a ConvTranspose with the 3x3 kernel padded to 4x4) and the
     ConvTranspose's (a 4x4 stride-2 conv as four plane passes of 2x2 taps, the P4 form) -- on the persistent kernel, from fragment
     operands packed on the device (prs2 / prct / prp4_frag_index).  Same bf16 mode with the persistent kernel switched off (variant 3:
     generic implicit-GEMM / free-running kernels, the [tap][N][K] operands): eps and every gradient must agree to bf16 noise --
-    a wrong tap, plane or fragment slot is an O(1) error.  Ragged tiles in the first case, the C5 per-GPU shape in the second."""
+    a wrong tap, plane or fragment slot is an O(1) error.  Ragged tiles in the first case, the C5 per-GPU shape in the second, C4's
+    architecture (192 / 384 / 768 / 3072 channels: half-padded N tiles, three and six 64-channel chunks) in the third."""
     import ctypes
-    sd = synth.synth_state_dict(synth.unet_param_spec(512, 128, ch_mult))
+    sd = synth.synth_state_dict(synth.unet_param_spec(512, base, ch_mult))
     g = torch.Generator("cpu").manual_seed(77)
     x_t = torch.randn((B, 3, H, W), generator=g); z = torch.from_numpy(synth.synth_z(B))
-    t = torch.tensor([5, 250, 600, 990]); target = torch.randn((B, 3, H, W), generator=g)
+    t = torch.tensor([5, 250, 600, 990][:B]); target = torch.randn((B, 3, H, W), generator=g)
     lib = _native.load_library()
     lib.ccn_internal_set_conv_variant.restype = ctypes.c_int
     lib.ccn_internal_set_conv_variant.argtypes = [ctypes.c_int]
     old = lib.ccn_internal_set_conv_variant(3)
     try:
-        l3, g3, e3 = grads_via_autograd(make_net(sd, 128, ch_mult, dtype="bf16"), x_t, z, t, target)
+        l3, g3, e3 = grads_via_autograd(make_net(sd, base, ch_mult, dtype="bf16"), x_t, z, t, target)
+        torch.cuda.empty_cache()
         lib.ccn_internal_set_conv_variant(4)
-        l4, g4, e4 = grads_via_autograd(make_net(sd, 128, ch_mult, dtype="bf16"), x_t, z, t, target)
+        l4, g4, e4 = grads_via_autograd(make_net(sd, base, ch_mult, dtype="bf16"), x_t, z, t, target)
     finally:
         lib.ccn_internal_set_conv_variant(old)
     assert float((e4 - e3).abs().max()) < 4e-2, float((e4 - e3).abs().max())
@@ -325,7 +327,7 @@ def test_stride2_and_convtranspose_steps_on_the_persistent_kernel_match_the_gene
         if e > worst[1]:
             worst = (k, e)
         assert e < 0.08, (k, e)
-    print(f"persistent vs generic kernels, bf16 step {ch_mult} {B}x{H}x{W}: eps max diff {float((e4 - e3).abs().max()):.2e}, "
+    print(f"persistent vs generic kernels, bf16 step base {base} {ch_mult} {B}x{H}x{W}: eps max diff {float((e4 - e3).abs().max()):.2e}, "
           f"worst gradient relative L2 difference {worst[1]:.3e} ({worst[0]})")
 
 
