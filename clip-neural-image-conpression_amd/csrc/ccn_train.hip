@@ -647,9 +647,13 @@ struct Walk {
                 }
             }
         }
-        if (launch && fwd_side_used) {                           // everything this forward put on the side stream: the backward pass waits for it
-            if (hipEventRecord(tr->pack_dg_done, tr->side) != hipSuccess) { err = "event record failed"; return false; }
-            tr->pack_dg_pending = true;
+        if (launch && (fwd_side_used || tr->pack_dg_pending)) {
+            // Everything this forward put on the side stream -- the data-gradient operands' repack (reads the parameters), the activated-
+            // tensor passes (write into the workspace) -- is joined HERE, on the caller's stream: the side work ended long before the
+            // last convs of the main chain do, so the wait is free, and whatever the caller does next with the parameters or the
+            // workspace (an optimizer step without a backward pass, freeing the workspace) is ordered behind it.
+            if (hipEventRecord(tr->pack_dg_done, tr->side) != hipSuccess || hipStreamWaitEvent(st, tr->pack_dg_done, 0) != hipSuccess) { err = "stream join failed"; return false; }
+            tr->pack_dg_pending = false;
         }
         return true;
     }
