@@ -1279,25 +1279,51 @@ hipError_t launch_nchw_to_nhwc_pad(int dtype, const float* x, void* dst, int B, 
 }
 
 // ---- small fp32 linears ---------------------------------------------------------------------------------------------------
-// y[r][n] = act(u), u = sum_k x[r][k] W[n][k] + b[n]; one wave per n, lanes stride K (as linear_kernel in ccn_kernels.hip)
+// y[r][n] = act(u), u = sum_k x[r][k] W[n][k] + b[n]; one wave per n.  The weight row is read ONCE for up to eight rows r, sixteen bytes per
+// lane and load, the loads of a row independent of each other (one scalar load in flight per row pass left time_proj.2 -- K = 2048, 512
+// waves -- at 57 us; conditioning is the first thing of the training step and nothing overlaps it)
 __global__ __launch_bounds__(256) void tlinear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
                                                            float* __restrict__ y, int ldy, float* __restrict__ u, int R, int K, int N, int silu)
 {
+    constexpr int RM = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
     const float* wrow = W + (size_t)n * K;
-    for (int rr = 0; rr < R; ++rr) {
-        const float* pa = x + (size_t)rr * ldx;
-        float acc = 0.f;
-        for (int k = lane; k < K; k += 64) acc = fmaf(pa[k], wrow[k], acc);
+    const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && (((size_t)x | (size_t)W) & 15) == 0;
+    for (int r0 = 0; r0 < R; r0 += RM) {
+        float acc[RM];
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
-        if (lane == 0) {
-            float v = acc + (bias ? bias[n] : 0.f);
-            if (u) u[(size_t)rr * ldy + n] = v;
-            if (silu) v = v / (1.0f + expf(-v));
-            y[(size_t)rr * ldy + n] = v;
+        for (int j = 0; j < RM; ++j) acc[j] = 0.f;
+        if (vec) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 w4 = *(const f32x4*)(wrow + k);
+#pragma unroll
+                for (int j = 0; j < RM; ++j) {
+                    if (r0 + j >= R) break;
+                    const f32x4 x4 = *(const f32x4*)(x + (size_t)(r0 + j) * ldx + k);
+                    acc[j] = fmaf(x4[0], w4[0], fmaf(x4[1], w4[1], fmaf(x4[2], w4[2], fmaf(x4[3], w4[3], acc[j]))));
+                }
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                const float w1 = wrow[k];
+#pragma unroll
+                for (int j = 0; j < RM; ++j) { if (r0 + j >= R) break; acc[j] = fmaf(x[(size_t)(r0 + j) * ldx + k], w1, acc[j]); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RM; ++j) {
+            if (r0 + j >= R) break;
+            float a = acc[j];
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) a += __shfl_xor(a, s2);
+            if (lane == 0) {
+                float v = a + (bias ? bias[n] : 0.f);
+                if (u) u[(size_t)(r0 + j) * ldy + n] = v;
+                if (silu) v = v / (1.0f + expf(-v));
+                y[(size_t)(r0 + j) * ldy + n] = v;
+            }
         }
     }
 }
