@@ -33,6 +33,7 @@ for p in (str(REPO), str(REPO / "clip-neural-image-conpression_amd")):
 import torch
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_TRAFFIC_TRAIN_FILE = "r03_pmc_traffic_train.json"
 
 
 def main() -> None:
@@ -135,6 +136,14 @@ def main() -> None:
             head = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 4), "traffic": None,
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 2)}
+        # HBM bytes per launch of the leading family from the --pmc passes of this workload (tools/profile_train.sh; a STORED figure)
+        pmc = REPO / "profiles" / PMC_TRAFFIC_TRAIN_FILE
+        if pmc.exists() and args.dtype == "bf16" and (B, S, args.base, ch_mult) == (4, 256, 128, (1, 2, 2)):
+            fam = json.loads(pmc.read_text()).get("families", {}).get(dom["name"])
+            if fam:
+                head["traffic"] = round((fam["read_mb_per_launch_corrected_x2"] + fam["write_mb_per_launch"]) * 1e6)
+                head["traffic_source"] = (f"stored: profiles/{PMC_TRAFFIC_TRAIN_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                          "average over every launch of the family; not this run)")
         roofline = {
             **head,
             "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),

@@ -11,7 +11,8 @@ fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 FAMS = {"conv_weight_grad": lambda k: "wgrad_bf16" in k, "weight_grad_reduce": lambda k: "wgrad_reduce" in k,
         "gn_bwd_reduce": lambda k: "gn_bwd_reduce" in k, "gn_bwd_apply": lambda k: "gn_bwd_apply" in k,
         "conv_pr": lambda k: "conv_pr_kernel" in k, "conv_ws_fr": lambda k: "conv_ws_kernel" in k or "conv_fr_kernel" in k,
-        "gn_act": lambda k: "gn_act_kernel" in k}
+        "gn_act": lambda k: "gn_act_kernel" in k or "gn_act_fused" in k, "stem_head": lambda k: "stem_kernel" in k or "head_kernel" in k,
+        "weight_repack": lambda k: "pack_group_kernel" in k, "adamw": lambda k: "adamw_kernel" in k}
 def totals(d, counter):
     tot = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -30,5 +31,6 @@ for fam in FAMS:
     n = f[fam][1]
     res[fam] = {"launches_profiled": n, "read_mb_per_launch_corrected_x2": round(2 * f[fam][0] * 1024 / n / 1e6, 2),
                 "write_mb_per_launch": round(w[fam][0] * 1024 / max(w[fam][1], 1) / 1e6, 2)}
-json.dump({"note": "separate --pmc passes, training step at 256 px / batch 4 / bf16; FETCH_SIZE doubled per the gfx950 note", "families": res}, open(out, "w"), indent=1)
+json.dump({"note": "separate --pmc passes, training step at 256 px / batch 4 / bf16; FETCH_SIZE doubled per the gfx950 note; per launch, averaged over every launch "
+                   "of the family in the profiled steps (all layer shapes)", "families": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -13,3 +13,9 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_bench_train_bf16
 python tools/trace_train.py $O/trace > $O/${R}_train_step_launch_by_launch.txt
 rm -rf $O/stats $O/trace
 ls -la $O
+# HBM bytes per launch of the kernel families (two --pmc passes, kernel trace only)
+(cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$O/pmc_fetch -- python3 $OLDPWD/bench_train.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$O/pmc_write -- python3 $OLDPWD/bench_train.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1)
+python tools/pmc_traffic_train.py $O/pmc_fetch $O/pmc_write $O/${R}_pmc_traffic_train.json > /dev/null
+rm -rf $O/pmc_fetch $O/pmc_write
+ls -la $O
