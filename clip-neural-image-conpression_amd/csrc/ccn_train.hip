@@ -476,7 +476,8 @@ struct Walk {
             return true;
         };
         const int dt = tr->cfg.dtype;
-        if (launch && in_kernel_stats_ok(x, x.C)) {
+        // (the second condition is run_conv's own size limit for the persistent kernel: past it the conv takes the table route below)
+        if (launch && in_kernel_stats_ok(x, x.C) && (double)B * x.H * x.W * w.Cout * tr->elem < 2.0e9) {
             // statistics in the conv itself; the side stream's pass writes the activated tensor AND the tables the backward pass reads
             const GsIn gs{x.part, x.n_sp, x.n_nt, x.bn, cpg, par(n.pg), par(n.pb), 1.0 / count};
             bool used = false;
